@@ -1,0 +1,345 @@
+"""CPU oracle: closed-form restatement of the reference's relevance-propagation hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``transformer-explainability_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it,
+and only as the checker / the timed CPU baseline, never as the product path.
+
+Every function restates one rule of hila-chefer/Transformer-Explainability (paths relative to
+the reference checkout) as plain fp32 torch-CPU arithmetic with no autograd.  The reference
+writes each rule as ``torch.autograd.grad`` over a re-built micro-graph; the closed forms below
+are algebraically the same and are pinned against the reference itself by
+``tests/golden/make_golden.py`` -> ``tests/golden/*.npz`` -> ``tests/test_oracle_golden.py``.
+
+Parity pinning status: the reference ships NO tests / golden vectors, so
+the pins are outputs of the reference run in the build container on seeded synthetic inputs
+(generator script committed next to the fixtures).
+
+Batch semantics: the reference is batch-1 only (ViT_explanation_generator.py:31-32,
+ViT_LRP.py:362-363; Add.relprop uses whole-tensor sums, modules/layers_ours.py:109-116).  The
+oracle defines a batch of B samples as B independent batch-1 problems: every reduction that the
+reference takes over "the whole tensor" is taken per sample here.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------------
+# a1  safe_divide                                   modules/layers_ours.py:10-13
+# --------------------------------------------------------------------------------------------
+def safe_divide(a: Tensor, b: Tensor) -> Tensor:
+    """``a / den * (b != 0)`` with ``den = b + 1e-9`` and ``den == 0 -> 1e-9``.
+
+    Reference: ``den = b.clamp(min=1e-9) + b.clamp(max=1e-9)`` -- one of the two clamps is always
+    the constant 1e-9 and the other is ``b``, so the sum is ``b + 1e-9`` rounded once in the
+    tensor dtype; ``den + den.eq(0) * 1e-9`` then replaces an exact zero by 1e-9.
+    """
+    eps = torch.tensor(1e-9, dtype=b.dtype)
+    den = b + eps
+    den = torch.where(den == 0, eps, den)
+    return a / den * (b != 0).to(b.dtype)
+
+
+# --------------------------------------------------------------------------------------------
+# a3  Linear.relprop        modules/layers_ours.py:207-230 (ours), modules/layers_lrp.py:188-211
+# --------------------------------------------------------------------------------------------
+def _linear_half(R: Tensor, px: Tensor, nx: Tensor, w1: Tensor, w2: Tensor, variant: str) -> Tensor:
+    # f(w1, w2, x1, x2) of layers_ours.py:215-223: Z1 = x1 w1^T, Z2 = x2 w2^T
+    Z1 = px.matmul(w1.t())
+    Z2 = nx.matmul(w2.t())
+    if variant == "ours":
+        S1 = safe_divide(R, Z1 + Z2)        # layers_ours.py:218-219
+        S2 = S1
+    elif variant == "lrp":
+        S1 = safe_divide(R, Z1)             # layers_lrp.py:199-200
+        S2 = safe_divide(R, Z2)
+    else:
+        raise ValueError(variant)
+    C1 = px * S1.matmul(w1)                 # x1 * autograd.grad(Z1, x1, S1)
+    C2 = nx * S2.matmul(w2)
+    return C1 + C2
+
+
+def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant: str = "ours") -> Tensor:
+    """R [..., out], X [..., in], W [out, in] -> [..., in].  Bias is ignored by the reference."""
+    beta = alpha - 1
+    pw = W.clamp(min=0)
+    nw = W.clamp(max=0)
+    px = X.clamp(min=0)
+    nx = X.clamp(max=0)
+    act = _linear_half(R, px, nx, pw, nw, variant)
+    if beta == 0:
+        # reference computes alpha*act - 0*inh (layers_ours.py:225-228); with finite inh that is
+        # alpha*act exactly, so the dead inhibitor half is not evaluated.
+        return alpha * act
+    inh = _linear_half(R, px, nx, nw, pw, variant)
+    return alpha * act - beta * inh
+
+
+# --------------------------------------------------------------------------------------------
+# a4  einsum / MatMul relprop (RelPropSimple)       modules/layers_ours.py:48-60,122-127
+#                                                   BERT_explainability/modules/layers_ours.py:89-91
+# --------------------------------------------------------------------------------------------
+def matmul_relprop(R: Tensor, X0: Tensor, X1: Tensor) -> Tuple[Tensor, Tensor]:
+    """Generic batched rule for ``Z = X0 @ X1`` (X0 [..., M, K], X1 [..., K, N], R [..., M, N]).
+
+    out0 = X0 * (S @ X1^T), out1 = X1 * (X0^T @ S), S = safe_divide(R, Z).  The callers halve both
+    outputs (ViT_LRP.py:161-162,172-173; BERT.py:373-374,392-393); that is NOT done here.
+    """
+    Z = X0.matmul(X1)
+    S = safe_divide(R, Z)
+    out0 = X0 * S.matmul(X1.transpose(-1, -2))
+    out1 = X1 * X0.transpose(-1, -2).matmul(S)
+    return out0, out1
+
+
+def einsum_av_relprop(R: Tensor, attn: Tensor, v: Tensor) -> Tuple[Tensor, Tensor]:
+    """einsum('bhij,bhjd->bhid').relprop  (ViT_LRP.py:160): returns (cam_attn, cam_v), un-halved."""
+    return matmul_relprop(R, attn, v)
+
+
+def einsum_qk_relprop(R: Tensor, q: Tensor, k: Tensor) -> Tuple[Tensor, Tensor]:
+    """einsum('bhid,bhjd->bhij').relprop  (ViT_LRP.py:171): returns (cam_q, cam_k), un-halved.
+
+    The second operand of the einsum is k [B,H,N,D] (not transposed), so the second output has
+    k's shape: cam_k = k * (S^T @ q).
+    """
+    Z = q.matmul(k.transpose(-1, -2))
+    S = safe_divide(R, Z)
+    cam_q = q * S.matmul(k)
+    cam_k = k * S.transpose(-1, -2).matmul(q)
+    return cam_q, cam_k
+
+
+# --------------------------------------------------------------------------------------------
+# a5  Add.relprop     modules/layers_ours.py:97-120 (ours) ; modules/layers_lrp.py:98-100 (lrp)
+# --------------------------------------------------------------------------------------------
+def _reduce_to(t: Tensor, shape: Sequence[int]) -> Tensor:
+    """Sum ``t`` down to broadcast-source ``shape`` (what autograd does for a broadcast operand)."""
+    while t.dim() > len(shape):
+        t = t.sum(0)
+    for d, s in enumerate(shape):
+        if s == 1 and t.shape[d] != 1:
+            t = t.sum(d, keepdim=True)
+    return t
+
+
+def _add_relprop_one(R: Tensor, X0: Tensor, X1: Tensor, variant: str) -> Tuple[Tensor, Tensor]:
+    Z = X0 + X1
+    S = safe_divide(R, Z)
+    a = X0 * _reduce_to(S, X0.shape)
+    b = X1 * _reduce_to(S, X1.shape)
+    if variant == "lrp":
+        return a, b
+    a_sum = a.sum()
+    b_sum = b.sum()
+    r_sum = R.sum()
+    a_fact = safe_divide(a_sum.abs(), a_sum.abs() + b_sum.abs()) * r_sum
+    b_fact = safe_divide(b_sum.abs(), a_sum.abs() + b_sum.abs()) * r_sum
+    a = a * safe_divide(a_fact, a_sum)
+    b = b * safe_divide(b_fact, b_sum)
+    return a, b
+
+
+def add_relprop(R: Tensor, X0: Tensor, X1: Tensor, variant: str = "ours") -> Tuple[Tensor, Tensor]:
+    """Per-sample Add rule.  dim 0 is the batch; X1 may be a broadcast operand (BERT attention
+    mask [B,1,1,N] against scores [B,H,N,N], BERT.py:342,386-388) or batch-less (ViT pos_embed
+    [1,N,C], ViT_LRP.py:311)."""
+    B = R.shape[0]
+    outs0, outs1 = [], []
+    for i in range(B):
+        x1 = X1[i:i + 1] if X1.shape[0] == B else X1
+        a, b = _add_relprop_one(R[i:i + 1], X0[i:i + 1], x1, variant)
+        outs0.append(a)
+        outs1.append(b)
+    return torch.cat(outs0, 0), torch.cat(outs1, 0)
+
+
+# --------------------------------------------------------------------------------------------
+# a6  Clone.relprop                                  modules/layers_ours.py:151-169
+# --------------------------------------------------------------------------------------------
+def clone_relprop(Rs: Sequence[Tensor], X: Tensor) -> Tensor:
+    """out = X * sum_i safe_divide(R_i, X); the sum is accumulated in list order (autograd
+    accumulates the cotangents of the ``num`` aliases of X in the order they were appended)."""
+    C = safe_divide(Rs[0], X)
+    for r in Rs[1:]:
+        C = C + safe_divide(r, X)
+    return X * C
+
+
+# --------------------------------------------------------------------------------------------
+# a7  IndexSelect.relprop                            modules/layers_ours.py:129-147
+# --------------------------------------------------------------------------------------------
+def index_select_relprop(R: Tensor, X: Tensor, dim: int, index: int) -> Tensor:
+    """R has size 1 along ``dim``; relevance lands on slot ``index`` of ``dim``, zeros elsewhere."""
+    idx = torch.tensor([index])
+    Z = X.index_select(dim, idx)
+    S = safe_divide(R, Z)
+    C = torch.zeros_like(X)
+    C.index_add_(dim, idx, S)
+    return X * C
+
+
+# --------------------------------------------------------------------------------------------
+# a10 tail: gradient x attention-relevance, clamp, head mean   ViT_LRP.py:357-366
+#                                                             ExplanationGenerator.py:47-56
+# --------------------------------------------------------------------------------------------
+def gradcam_headmean(grad: Tensor, cam: Tensor) -> Tensor:
+    """grad, cam [B,H,N,N] -> [B,N,N]: per sample ``(grad*cam).clamp(min=0).mean(dim=heads)``."""
+    return (grad * cam).clamp(min=0).mean(dim=1)
+
+
+# --------------------------------------------------------------------------------------------
+# a11 rollout      ViT_LRP.py:38-49 (no normalisation) ; ExplanationGenerator.py:7-18 (row-normalised)
+# --------------------------------------------------------------------------------------------
+def rollout(cams: Sequence[Tensor], start_layer: int = 0, normalise: bool = False) -> Tensor:
+    """cams: L tensors [B,N,N].  Returns the joint matrix [B,N,N]."""
+    N = cams[0].shape[1]
+    eye = torch.eye(N, dtype=cams[0].dtype).expand_as(cams[0])
+    mats = [c + eye for c in cams]
+    if normalise:
+        mats = [m / m.sum(dim=-1, keepdim=True) for m in mats]
+    joint = mats[start_layer]
+    for i in range(start_layer + 1, len(mats)):
+        joint = mats[i].bmm(joint)
+    return joint
+
+
+def vit_attribution_tail(grads: Sequence[Tensor], cams: Sequence[Tensor], start_layer: int = 0) -> Tensor:
+    """ViT_LRP.py:357-369 -> [B, N-1]."""
+    layer_cams = [gradcam_headmean(g, c) for g, c in zip(grads, cams)]
+    return rollout(layer_cams, start_layer, normalise=False)[:, 0, 1:]
+
+
+def bert_attribution_tail(grads: Sequence[Tensor], cams: Sequence[Tensor], start_layer: int = 11) -> Tensor:
+    """ExplanationGenerator.py:47-59 -> [B, N] (row-normalised rollout + CLS fix-up)."""
+    layer_cams = [gradcam_headmean(g, c) for g, c in zip(grads, cams)]
+    joint = rollout(layer_cams, start_layer, normalise=True).clone()
+    row0 = joint[:, 0]
+    joint[:, 0, 0] = row0.min(dim=-1).values
+    return joint[:, 0]
+
+
+# --------------------------------------------------------------------------------------------
+# a8/a9/a10 composition: ViT block / model relprop      ViT_LRP.py:69-74,154-177,203-213,324-369
+# --------------------------------------------------------------------------------------------
+def _heads(x: Tensor, H: int) -> Tensor:            # 'b n (h d) -> b h n d'
+    B, N, C = x.shape
+    return x.reshape(B, N, H, C // H).permute(0, 2, 1, 3)
+
+
+def _unheads(x: Tensor) -> Tensor:                  # 'b h n d -> b n (h d)'
+    B, H, N, D = x.shape
+    return x.permute(0, 2, 1, 3).reshape(B, N, H * D)
+
+
+def vit_block_relprop(cam: Tensor, blk: dict, num_heads: int, alpha: float = 1.0,
+                      variant: str = "ours") -> Tuple[Tensor, Tensor]:
+    """One Block.relprop (ViT_LRP.py:203-213).  ``blk`` holds the cached forward tensors:
+
+      add2_x0, add2_x1, fc2_x, fc2_w, fc1_x, fc1_w, clone2_x, add1_x0, add1_x1, proj_x, proj_w,
+      attn [B,H,N,N], qkv_out [B,N,3C] (output of the qkv Linear), qkv_x, qkv_w, clone1_x
+
+    Returns (cam, attn_cam).
+    """
+    cam1, cam2 = add_relprop(cam, blk["add2_x0"], blk["add2_x1"], variant)
+    cam2 = linear_relprop(cam2, blk["fc2_x"], blk["fc2_w"], alpha, variant)
+    cam2 = linear_relprop(cam2, blk["fc1_x"], blk["fc1_w"], alpha, variant)
+    cam = clone_relprop([cam1, cam2], blk["clone2_x"])
+
+    cam1, cam2 = add_relprop(cam, blk["add1_x0"], blk["add1_x1"], variant)
+    cam2 = linear_relprop(cam2, blk["proj_x"], blk["proj_w"], alpha, variant)
+    B, N, C = cam2.shape
+    qkv = blk["qkv_out"].reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    c_attn, c_v = einsum_av_relprop(_heads(cam2, num_heads), blk["attn"], v)
+    c_attn = c_attn / 2
+    c_v = c_v / 2
+    attn_cam = c_attn
+    c_q, c_k = einsum_qk_relprop(c_attn, q, k)
+    c_q = c_q / 2
+    c_k = c_k / 2
+    cam_qkv = torch.cat([_unheads(c_q), _unheads(c_k), _unheads(c_v)], dim=-1)
+    cam2 = linear_relprop(cam_qkv, blk["qkv_x"], blk["qkv_w"], alpha, variant)
+    cam = clone_relprop([cam1, cam2], blk["clone1_x"])
+    return cam, attn_cam
+
+
+def vit_relprop(one_hot: Tensor, cache: dict, num_heads: int, start_layer: int = 0,
+                alpha: float = 1.0, variant: str = "ours") -> dict:
+    """VisionTransformer.relprop(method='transformer_attribution') (ViT_LRP.py:324-369).
+
+    cache: head_x [B,C], head_w [K,C], pool_x [B,N,C], blocks: list of dicts (see
+    vit_block_relprop) each also holding ``attn_grad`` [B,H,N,N].
+    """
+    cam = linear_relprop(one_hot, cache["head_x"], cache["head_w"], alpha, variant)
+    cam = index_select_relprop(cam.unsqueeze(1), cache["pool_x"], 1, 0)
+    attn_cams = [None] * len(cache["blocks"])
+    for i in reversed(range(len(cache["blocks"]))):
+        cam, attn_cams[i] = vit_block_relprop(cam, cache["blocks"][i], num_heads, alpha, variant)
+    grads = [b["attn_grad"] for b in cache["blocks"]]
+    out = vit_attribution_tail(grads, attn_cams, start_layer)
+    return {"map": out, "cam": cam, "attn_cams": attn_cams}
+
+
+# --------------------------------------------------------------------------------------------
+# BERT layer / model relprop            BERT.py:521-530,240-247,367-409,427-434,451-456,474-487
+# --------------------------------------------------------------------------------------------
+def bert_layer_relprop(cam: Tensor, lay: dict, num_heads: int, alpha: float = 1.0,
+                       variant: str = "ours") -> Tuple[Tensor, Tensor]:
+    """``lay`` holds: out_add_x0, out_add_x1, out_dense_x, out_dense_w, inter_x, inter_w, clone_x,
+    att_add_x0, att_add_x1, att_dense_x, att_dense_w, probs [B,H,N,N], q, k, v [B,N,C] (outputs of
+    the three Linears), mask_add_x0 [B,H,N,N] (scaled scores) or None, ext_mask [B,1,1,N] or None,
+    q_x, q_w, k_x, k_w, v_x, v_w, self_clone_x, att_clone_x.  Returns (cam, attn_cam)."""
+    c1, c2 = add_relprop(cam, lay["out_add_x0"], lay["out_add_x1"], variant)          # BertOutput :474
+    c1 = linear_relprop(c1, lay["out_dense_x"], lay["out_dense_w"], alpha, variant)
+    c1 = linear_relprop(c1, lay["inter_x"], lay["inter_w"], alpha, variant)           # :451
+    cam = clone_relprop([c1, c2], lay["clone_x"])                                      # BertLayer :527
+    c1, c2 = add_relprop(cam, lay["att_add_x0"], lay["att_add_x1"], variant)           # BertSelfOutput :427
+    c1 = linear_relprop(c1, lay["att_dense_x"], lay["att_dense_w"], alpha, variant)
+    q, k, v = (_heads(lay[n], num_heads) for n in ("q", "k", "v"))
+    cam1, cam_v = matmul_relprop(_heads(c1, num_heads), lay["probs"], v)               # :371
+    cam1 = cam1 / 2
+    cam_v = cam_v / 2
+    attn_cam = cam1
+    if lay.get("ext_mask") is not None:
+        cam1, _ = add_relprop(cam1, lay["mask_add_x0"], lay["ext_mask"], variant)      # :386-388
+    cq, ckt = matmul_relprop(cam1, q, k.transpose(-1, -2))                             # :391
+    cq = cq / 2
+    ckt = ckt / 2
+    rq = linear_relprop(_unheads(cq), lay["q_x"], lay["q_w"], alpha, variant)
+    rk = linear_relprop(_unheads(ckt.transpose(-1, -2)), lay["k_x"], lay["k_w"], alpha, variant)
+    rv = linear_relprop(_unheads(cam_v), lay["v_x"], lay["v_w"], alpha, variant)
+    c1 = clone_relprop([rq, rk, rv], lay["self_clone_x"])                              # :407
+    cam = clone_relprop([c1, c2], lay["att_clone_x"])                                  # BertAttention :247
+    return cam, attn_cam
+
+
+def bert_relprop(one_hot: Tensor, cache: dict, num_heads: int, start_layer: int = 11,
+                 alpha: float = 1.0, variant: str = "ours") -> dict:
+    """BertForSequenceClassification.relprop (:83-88) + Generator.generate_LRP tail."""
+    cam = linear_relprop(one_hot, cache["cls_x"], cache["cls_w"], alpha, variant)
+    cam = linear_relprop(cam, cache["pool_dense_x"], cache["pool_dense_w"], alpha, variant)   # BERT.py:181
+    cam = index_select_relprop(cam.unsqueeze(1), cache["pool_x"], 1, 0)
+    attn_cams = [None] * len(cache["layers"])
+    for i in reversed(range(len(cache["layers"]))):
+        cam, attn_cams[i] = bert_layer_relprop(cam, cache["layers"][i], num_heads, alpha, variant)
+    grads = [l["attn_grad"] for l in cache["layers"]]
+    out = bert_attribution_tail(grads, attn_cams, start_layer)
+    return {"map": out, "cam": cam, "attn_cams": attn_cams}
+
+
+# --------------------------------------------------------------------------------------------
+# downstream consumer: bilinear x16 + min-max      imagenet_seg_eval.py:214-217
+# --------------------------------------------------------------------------------------------
+def minmax_normalise(m: Tensor) -> Tensor:
+    """Per-map min-max normalisation used by the parity statistic."""
+    flat = m.reshape(m.shape[0], -1)
+    lo = flat.min(dim=1, keepdim=True).values
+    hi = flat.max(dim=1, keepdim=True).values
+    return ((flat - lo) / (hi - lo)).reshape(m.shape)

@@ -1,0 +1,76 @@
+"""pytest configuration: markers, repo-root imports, golden-fixture helpers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def load_golden(name):
+    """npz -> dict of torch tensors (0-d arrays stay python floats)."""
+    z = np.load(os.path.join(GOLDEN, name))
+    out = {}
+    for k in z.files:
+        a = z[k]
+        out[k] = float(a) if a.ndim == 0 else torch.from_numpy(a.copy())
+    return out
+
+
+def unflatten_cache(flat, prefix):
+    """Inverse of make_golden.flatten_cache: 'p.blocks.0.attn' -> {'blocks': [{'attn': ...}]}."""
+    root = {}
+    for key, val in flat.items():
+        if not key.startswith(prefix):
+            continue
+        parts = key[len(prefix):].split(".")
+        node = root
+        i = 0
+        while i < len(parts) - 1:
+            name = parts[i]
+            if i + 1 < len(parts) - 0 and parts[i + 1].isdigit():
+                lst = node.setdefault(name, [])
+                idx = int(parts[i + 1])
+                while len(lst) <= idx:
+                    lst.append({})
+                node = lst[idx]
+                i += 2
+            else:
+                node = node.setdefault(name, {})
+                i += 1
+        node[parts[-1]] = val
+    return root
+
+
+@pytest.fixture(scope="session")
+def golden_rules():
+    return load_golden("rules.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_vit_tiny():
+    return load_golden("vit_tiny.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_bert_tiny():
+    return load_golden("bert_tiny.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_vit_b16():
+    return load_golden("vit_b16.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_bert_base():
+    return load_golden("bert_base.npz")

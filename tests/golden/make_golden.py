@@ -1,0 +1,295 @@
+#!/usr/bin/env python
+"""Generate the committed golden fixtures by running the UNMODIFIED reference on CPU.
+
+    python tests/golden/make_golden.py            # needs /root/reference (build container only)
+
+The reference ships no tests or golden vectors, so parity is pinned on
+these outputs of the reference itself: seeded synthetic weights (oracle/ref_harness.synthetic_init)
+and seeded ``randn`` inputs, torch CPU fp32.  Fixtures:
+
+  rules.npz       every relprop rule class of modules/layers_ours.py, modules/layers_lrp.py and the
+                  BERT copies, called directly (inputs + outputs)
+  vit_tiny.npz    3-block ViT (dim 64, 4 heads, 17 tokens): full relprop cache + every intermediate
+  vit_b16.npz     ViT-B/16 224^2: generate_LRP maps for 2 images (weights regenerated from the seed)
+  bert_tiny.npz   3-layer BERT (dim 64, 4 heads, 24 tokens, 6 padded): full cache + intermediates
+  bert_base.npz   BERT-base, 128 tokens (28 padded): generate_LRP vectors (weights from the seed)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from oracle import ref_harness as rh  # noqa: E402
+
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def flatten_cache(prefix, cache, out):
+    for k, v in cache.items():
+        if isinstance(v, list):
+            for i, item in enumerate(v):
+                flatten_cache(f"{prefix}{k}.{i}.", item, out)
+        elif v is None:
+            continue
+        else:
+            out[prefix + k] = npy(v)
+
+
+# ------------------------------------------------------------------------------------------
+def make_rules():
+    vit = rh.load_reference_vit()
+    bert = rh.load_reference_bert()
+    out = {}
+    r = rh.seeded_randn
+
+    # ---- Linear (ours / lrp), alpha 1 and 2, with exact zeros sprinkled into X and R
+    for variant, mod in (("ours", vit["layers_ours"]), ("lrp", vit["layers_lrp"])):
+        lin = mod.Linear(24, 40)
+        with torch.no_grad():
+            lin.weight.copy_(0.3 * r((40, 24), 11))
+            lin.bias.copy_(0.1 * r((40,), 12))
+        X = r((2, 5, 24), 13)
+        X[0, 0, :4] = 0.0
+        R = r((2, 5, 40), 14) * 0.01
+        R[1, 2, :3] = 0.0
+        lin(X)
+        out[f"linear_{variant}.X"] = npy(X)
+        out[f"linear_{variant}.W"] = npy(lin.weight)
+        out[f"linear_{variant}.R"] = npy(R)
+        for alpha in (1, 2):
+            out[f"linear_{variant}.out_a{alpha}"] = npy(lin.relprop(R, alpha))
+
+    # ---- einsum rules of ViT attention (AV and QK^T)
+    E = vit["layers_ours"]
+    B, H, N, D = 2, 3, 7, 8
+    q, k, v = r((B, H, N, D), 21), r((B, H, N, D), 22), r((B, H, N, D), 23)
+    attn = torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1)
+    m2 = E.einsum('bhij,bhjd->bhid')
+    m2([attn, v])
+    Rav = r((B, H, N, D), 24) * 0.01
+    c_attn, c_v = m2.relprop(Rav, 1)
+    out.update({"av.attn": npy(attn), "av.v": npy(v), "av.R": npy(Rav),
+                "av.out0": npy(c_attn), "av.out1": npy(c_v)})
+    m1 = E.einsum('bhid,bhjd->bhij')
+    m1([q, k])
+    Rqk = r((B, H, N, N), 25) * 0.01
+    c_q, c_k = m1.relprop(Rqk, 1)
+    out.update({"qk.q": npy(q), "qk.k": npy(k), "qk.R": npy(Rqk),
+                "qk.out0": npy(c_q), "qk.out1": npy(c_k)})
+
+    # ---- BERT MatMul with an explicitly transposed second operand (BERT.py:338)
+    MB = bert["layers_ours"]
+    mm = MB.MatMul()
+    kt = k.transpose(-1, -2)
+    mm([q, kt])
+    o0, o1 = mm.relprop(Rqk, 1)
+    out.update({"matmul_qkT.out0": npy(o0), "matmul_qkT.out1": npy(o1)})
+
+    # ---- Add ours / lrp (batch 1: whole-tensor sums) and BERT broadcast-mask Add
+    for variant, mod in (("ours", vit["layers_ours"]), ("lrp", vit["layers_lrp"])):
+        add = mod.Add()
+        X0, X1 = r((1, 9, 16), 31), r((1, 9, 16), 32)
+        X0[0, 0, 0] = 0.0
+        X1[0, 0, 0] = 0.0          # exact-zero denominator
+        Radd = r((1, 9, 16), 33) * 0.01
+        add([X0, X1])
+        a, b = add.relprop(Radd, 1)
+        out.update({f"add_{variant}.X0": npy(X0), f"add_{variant}.X1": npy(X1), f"add_{variant}.R": npy(Radd),
+                    f"add_{variant}.out0": npy(a), f"add_{variant}.out1": npy(b)})
+    addm = MB.Add()
+    S0 = r((1, 3, 7, 7), 34)
+    msk = torch.zeros(1, 1, 1, 7)
+    msk[..., 5:] = -10000.0
+    Rm = r((1, 3, 7, 7), 35) * 0.01
+    addm([S0, msk])
+    a, b = addm.relprop(Rm, 1)
+    out.update({"add_mask.X0": npy(S0), "add_mask.X1": npy(msk), "add_mask.R": npy(Rm),
+                "add_mask.out0": npy(a), "add_mask.out1": npy(b)})
+
+    # ---- Clone (2 and 3 aliases)
+    for num in (2, 3):
+        cl = E.Clone()
+        Xc = r((2, 5, 12), 41)
+        Xc[0, 0, 0] = 0.0
+        cl(Xc, num)
+        Rs = [r((2, 5, 12), 42 + i) * 0.01 for i in range(num)]
+        out[f"clone{num}.X"] = npy(Xc)
+        for i, t in enumerate(Rs):
+            out[f"clone{num}.R{i}"] = npy(t)
+        out[f"clone{num}.out"] = npy(cl.relprop(Rs, 1))
+
+    # ---- IndexSelect (token 0 of dim 1)
+    isel = E.IndexSelect()
+    Xi = r((2, 5, 12), 51)
+    isel(Xi, 1, torch.tensor(0))
+    Ri = r((2, 1, 12), 52) * 0.01
+    out.update({"index_select.X": npy(Xi), "index_select.R": npy(Ri),
+                "index_select.out": npy(isel.relprop(Ri, 1))})
+    np.savez_compressed(os.path.join(HERE, "rules.npz"), **out)
+    print("rules.npz", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------------------
+def run_vit(model, gen_mod, x, method, start_layer, index=None):
+    """One reference generate_LRP call per sample (the reference is batch-1 only)."""
+    gen = gen_mod.LRP(model)
+    maps = []
+    for i in range(x.shape[0]):
+        idx = None if index is None else int(index[i])
+        maps.append(gen.generate_LRP(x[i:i + 1], index=idx, method=method, start_layer=start_layer).detach())
+    return torch.cat(maps, 0)
+
+
+def make_vit_tiny():
+    vit = rh.load_reference_vit()
+    out = {}
+    cfg = dict(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10, qkv_bias=True)
+    x = rh.seeded_randn((2, 3, 32, 32), 1)
+    out["x"] = npy(x)
+    for variant, modname, method in (("ours", "ViT_LRP", "transformer_attribution"), ("lrp", "ViT_orig_LRP", "grad")):
+        model = vit[modname].VisionTransformer(**cfg).eval()
+        rh.synthetic_init(model, 0)
+        out[f"{variant}.state_checksum"] = np.float64(rh.state_checksum(model))
+        out[f"{variant}.logits"] = npy(model(x))
+        for sl in (0, 1):
+            out[f"{variant}.map_sl{sl}"] = npy(run_vit(model, vit["gen"], x, method, sl))
+        out[f"{variant}.map_sl0_idx3"] = npy(run_vit(model, vit["gen"], x, method, 0, index=[3, 3]))
+        out[f"{variant}.rollout_sl0"] = npy(run_vit(model, vit["gen"], x, "rollout", 0))
+        out[f"{variant}.last_layer"] = npy(run_vit(model, vit["gen"], x[:1], "last_layer", 0).reshape(1, -1))
+        # full cache + intermediates of sample 0 (start_layer 0, argmax class)
+        gen = vit["gen"].LRP(model)
+        gen.generate_LRP(x[:1], method=method, start_layer=0)
+        flatten_cache(f"{variant}.cache.", rh.vit_cache_from_reference(model), out)
+        for i, blk in enumerate(model.blocks):
+            out[f"{variant}.attn_cam.{i}"] = npy(blk.attn.get_attn_cam())
+            out[f"{variant}.v_cam.{i}"] = npy(blk.attn.get_v_cam())
+        logits = model(x[:1])
+        oh = torch.zeros(1, 10)
+        oh[0, logits.argmax(-1)] = 1
+        # final relevance at the block-stack input: rerun plain relprop and capture the token cam
+        model.zero_grad()
+        (oh * model(x[:1])).sum().backward()
+        cam = oh
+        cam = model.head.relprop(cam, alpha=1)
+        cam = model.pool.relprop(cam.unsqueeze(1), alpha=1)
+        for blk in reversed(model.blocks):
+            cam = blk.relprop(cam, alpha=1)
+        out[f"{variant}.cam_tokens"] = npy(cam)
+        if variant == "ours":
+            for k_, v_ in model.state_dict().items():
+                out[f"state.{k_}"] = npy(v_)
+    np.savez_compressed(os.path.join(HERE, "vit_tiny.npz"), **out)
+    print("vit_tiny.npz", len(out), "arrays")
+
+
+def make_vit_b16():
+    vit = rh.load_reference_vit()
+    out = {}
+    model = vit["ViT_LRP"].vit_base_patch16_224(pretrained=False).eval()
+    rh.synthetic_init(model, 0)
+    out["state_checksum"] = np.float64(rh.state_checksum(model))
+    x = rh.seeded_randn((2, 3, 224, 224), 1)
+    out["logits"] = npy(model(x))
+    for sl in (0, 1):
+        out[f"map_sl{sl}"] = npy(run_vit(model, vit["gen"], x, "transformer_attribution", sl))
+    # per-block scalar fingerprints of sample 1's attn_cam (localises a mismatch without big files)
+    out["attn_cam_abs_sum"] = np.array([float(b.attn.get_attn_cam().double().abs().sum()) for b in model.blocks])
+    out["attn_cam_row0"] = np.stack([npy(b.attn.get_attn_cam()[0, :, 0, :]) for b in model.blocks])
+    np.savez_compressed(os.path.join(HERE, "vit_b16.npz"), **out)
+    print("vit_b16.npz", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------------------
+def bert_inputs(B, N, pad, vocab, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, vocab, (B, N), generator=g)
+    mask = torch.ones(B, N)
+    if pad:
+        mask[:, N - pad:] = 0
+    return ids, mask
+
+
+def run_bert(model, gen_mod, ids, mask, start_layer, index=None):
+    gen = gen_mod.Generator(model)
+    outs = []
+    for i in range(ids.shape[0]):
+        idx = None if index is None else int(index[i])
+        outs.append(gen.generate_LRP(input_ids=ids[i:i + 1], attention_mask=mask[i:i + 1], index=idx,
+                                     start_layer=start_layer).detach().clone())
+    return torch.cat(outs, 0)
+
+
+def make_bert(tiny: bool):
+    bert = rh.load_reference_bert()
+    from transformers import BertConfig
+    out = {}
+    if tiny:
+        cfg = BertConfig(vocab_size=100, hidden_size=64, num_hidden_layers=3, num_attention_heads=4,
+                         intermediate_size=128, max_position_embeddings=40, num_labels=2)
+        ids, mask = bert_inputs(2, 24, 6, 100, 1)
+        starts = (0, 2)
+    else:
+        cfg = BertConfig(num_labels=2)
+        ids, mask = bert_inputs(1, 128, 28, 20000, 1)
+        starts = (0, 11)
+    cfg.return_dict = False
+    model = bert["cls"].BertForSequenceClassification(cfg).eval()
+    rh.synthetic_init(model, 0)
+    out["state_checksum"] = np.float64(rh.state_checksum(model))
+    out["input_ids"] = npy(ids)
+    out["attention_mask"] = npy(mask)
+    out["logits"] = npy(model(input_ids=ids, attention_mask=mask)[0])
+    for sl in starts:
+        out[f"map_sl{sl}"] = npy(run_bert(model, bert["gen"], ids, mask, sl))
+    # unmasked path (attention_mask=None is replaced by ones inside BertModel.forward, BERT.py:592)
+    out[f"map_nomask_sl{starts[0]}"] = npy(run_bert(model, bert["gen"], ids, torch.ones_like(mask), starts[0]))
+    gen = bert["gen"].Generator(model)
+    gen.generate_LRP(input_ids=ids[:1], attention_mask=mask[:1], start_layer=starts[0])
+    if tiny:
+        flatten_cache("cache.", rh.bert_cache_from_reference(model), out)
+        for k_, v_ in model.state_dict().items():
+            out[f"state.{k_}"] = npy(v_)
+    for i, lay in enumerate(model.bert.encoder.layer):
+        cam = lay.attention.self.get_attn_cam()
+        if tiny:
+            out[f"attn_cam.{i}"] = npy(cam)
+        else:
+            out[f"attn_cam_row0.{i}"] = npy(cam[0, :, 0, :])
+    logits = model(input_ids=ids[:1], attention_mask=mask[:1])[0]
+    oh = torch.zeros(1, 2)
+    oh[0, logits.argmax(-1)] = 1
+    model.zero_grad()
+    (oh * logits).sum().backward()
+    out["cam_tokens_sum"] = np.float64(model.relprop(oh, alpha=1).double().sum())
+    if tiny:
+        out["cam_tokens"] = npy(model.relprop(oh, alpha=1))
+    name = "bert_tiny.npz" if tiny else "bert_base.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, len(out), "arrays")
+
+
+if __name__ == "__main__":
+    if not rh.reference_available():
+        sys.exit("reference checkout not found at " + rh.REFERENCE_ROOT)
+    which = sys.argv[1:] or ["rules", "vit_tiny", "vit_b16", "bert_tiny", "bert_base"]
+    if "rules" in which:
+        make_rules()
+    if "vit_tiny" in which:
+        make_vit_tiny()
+    if "vit_b16" in which:
+        make_vit_b16()
+    if "bert_tiny" in which:
+        make_bert(True)
+    if "bert_base" in which:
+        make_bert(False)
