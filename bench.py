@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- relevance maps/sec for ViT-B/16 224^2 at batch 64 per GPU (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
+stock PyTorch-ROCm forward + attention-gradient backward, then the HIP relprop rules, the
+gradient x relevance head-mean and the rollout chain (LRP.generate_LRP, method
+"transformer_attribution", start_layer 1 as baselines/ViT/imagenet_seg_eval.py:196 of the reference calls
+it).  Nothing is skipped: all 12 blocks are propagated, fp32 end to end.
+
+Weak scaling: every rank runs the same batch size on its own images; the only communication is one
+all_gather (RCCL) of the finished [B,196] maps of the last step, inside the timed region.
+
+The JSON line also carries
+  roofline      the dominant kernel (Linear.relprop C-pass, fp32 MFMA): algorithmic FLOPs per launch over
+                the launch duration measured with HIP events on the launch stream, during the timed steps
+  cpu_baseline  the same path on the host cores of this box: stock PyTorch CPU fwd/bwd + the CPU oracle's
+                relprop (kind "port"), or the reference itself when /root/reference exists (kind
+                "reference"); rank 0, N = 1 only, bounded to a few maps
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+
+
+class KernelTimer:
+    """Brackets single kernel launches with HIP events recorded on torch's current stream (the stream
+    the C ABI launches on).  Events are resolved after the timed region's final synchronise."""
+
+    def __init__(self):
+        self.records = []          # (name, flops, start_event, end_event)
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def __call__(self, name, flops):
+        if not self.enabled:
+            yield
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        yield
+        e.record()
+        self.records.append((name, flops, s, e))
+
+    def summary(self, name):
+        rows = [(f, s.elapsed_time(e) * 1e-3) for n, f, s, e in self.records if n == name]
+        if not rows:
+            return None
+        flops = sum(f for f, _ in rows)
+        secs = sum(t for _, t in rows)
+        return {"launches": len(rows), "avg_us": secs / len(rows) * 1e6, "tflops": flops / secs / 1e12,
+                "flops_per_launch_avg": flops / len(rows)}
+
+
+def cpu_baseline(args, model_cpu_state, n_maps=3):
+    """Time the CPU path on this box's host cores: one sample at a time (the reference is batch-1)."""
+    from oracle import ref_harness as rh
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = torch.stack([synthetic_image(i) for i in range(n_maps + 1)])
+    if rh.reference_available() and args.cpu_baseline != "port":
+        mods = rh.load_reference_vit()
+        model = mods["ViT_LRP"].vit_base_patch16_224(pretrained=False).eval()
+        model.load_state_dict(model_cpu_state)
+        gen = mods["gen"].LRP(model)
+        times = []
+        for i in range(n_maps + 1):
+            t0 = time.perf_counter()
+            gen.generate_LRP(x[i:i + 1], method="transformer_attribution", start_layer=args.start_layer)
+            times.append(time.perf_counter() - t0)
+        kind = "reference"
+    else:
+        from transformer_explainability_amd import vit
+        from oracle import relprop_oracle as O
+        from oracle.model_cache import vit_cache_from_model
+        model = vit.vit_base_patch16_224().eval()
+        model.load_state_dict(model_cpu_state)
+        times = []
+        for i in range(n_maps + 1):
+            t0 = time.perf_counter()
+            out = model(x[i:i + 1])
+            oh = torch.zeros_like(out)
+            oh.scatter_(1, out.argmax(-1, keepdim=True), 1.0)
+            grads = torch.autograd.grad((oh * out).sum(), [b.attn.get_attn() for b in model.blocks])
+            for b, g in zip(model.blocks, grads):
+                b.attn.save_attn_gradients(g)
+            O.vit_relprop(oh, vit_cache_from_model(model), num_heads=12, start_layer=args.start_layer)
+            times.append(time.perf_counter() - t0)
+        kind = "port"
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "maps/s", "cores": cores, "kind": kind,
+            "sample": f"{n_maps} ViT-B/16 224^2 maps, batch 1, after 1 warm-up; median {med:.3f} s/map, "
+                      f"torch CPU fp32 with {cores} threads"}
+
+
+def synthetic_image(global_index, shape=(3, 224, 224), seed=1):
+    g = torch.Generator().manual_seed(seed * 1_000_003 + global_index)
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--start-layer", type=int, default=1)
+    ap.add_argument("--cpu-baseline", choices=["auto", "port", "off"], default="auto")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import __graft_entry__
+    import transformer_explainability_amd as te
+    from transformer_explainability_amd import ops, parallel, vit
+    from transformer_explainability_amd.generators import LRP
+
+    rank, world, local = parallel.init_distributed()
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        torch.distributed.barrier()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    te._lib.require_device()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(0)
+    model = vit.vit_base_patch16_224().eval()
+    with torch.no_grad():          # non-trivial biases / LayerNorm scales so every path is exercised
+        for n_, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.02 * torch.randn_like(p))
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model.to(dev)
+    B = args.batch
+    x = torch.stack([synthetic_image(rank * B + i) for i in range(B)]).to(dev)
+    lrp = LRP(model)
+
+    timer = KernelTimer()
+    if not args.no_roofline:
+        ops.KERNEL_TIMER = timer
+
+    def step():
+        return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
+
+    for _ in range(args.warmup):
+        maps = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        maps = step()
+    gathered = parallel.gather_maps(maps, world * B)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    ops.KERNEL_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert gathered.shape == (world * B, 196) and torch.isfinite(gathered).all()
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "relevance maps/sec (ViT-B/16 224^2, batch 64 per GPU, generate_LRP transformer_attribution)",
+            "value": value, "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ViT-B/16 224^2 batch 64 on 1xMI355X: stock fwd + attn-grad bwd + fp32 relprop/"
+                                   "head-mean/rollout HIP kernels (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "global_batch": world * B, "tokens": 197, "blocks": 12,
+                       "start_layer": args.start_layer, "parallelism": f"dp{world} (independent samples, one "
+                                                                      f"all_gather of the maps)"},
+        }
+        roof = None
+        cp = timer.summary("linear_cpass")
+        zp = timer.summary("linear_zpass")
+        if cp:
+            roof = {"bound": "mfma", "kernel": "linear_k2_kernel<0,false,false> (Linear.relprop C-pass)",
+                    "achieved": cp["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": cp["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "launches_timed": cp["launches"], "avg_launch_us": cp["avg_us"],
+                    "algorithmic_flops_per_launch_avg": cp["flops_per_launch_avg"],
+                    "zpass": {"achieved": zp["tflops"], "avg_launch_us": zp["avg_us"]} if zp else None}
+        line["roofline"] = roof
+        base = None
+        if world == 1 and args.cpu_baseline != "off":
+            base = cpu_baseline(args, cpu_state)
+        line["cpu_baseline"] = base
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * te_relprop.h -- C ABI of libte_relprop.so: the MI355X (gfx950) relevance-propagation hot path of
+ * hila-chefer/Transformer-Explainability ("transformer_attribution": LRP relprop rules ->
+ * gradient x attention head-mean -> rollout).
+ *
+ * Drop-in boundary.  The reference is pure Python; every entry point below replaces the body of one
+ * `relprop` method (or one tail function) that the reference expresses as torch.autograd.grad on a
+ * re-built micro-graph.  The reference-side binding is a ctypes stub; the
+ * shipped host side is transformer-explainability_amd/ (same class / method names as the reference).
+ *
+ * Conventions
+ *   - all tensors are fp32, row-major, device (HBM) pointers; shapes are int64 element counts,
+ *     strides are in ELEMENTS; the innermost dimension is always contiguous.
+ *   - BATCH SEMANTICS: the reference is batch-1 only (ViT_explanation_generator.py:31-32); a batch
+ *     of B samples here means B independent batch-1 problems -- every "whole tensor" reduction of
+ *     the reference (Add.relprop sums, modules/layers_ours.py:109-116) is taken per sample.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises,
+ *     allocates, frees, or keeps a pointer after it returns; the library has no global state.
+ *   - scratch memory is caller-provided: query te_<op>_workspace_bytes(...) and pass a device
+ *     buffer of at least that size (16-byte aligned).  Ops without a query need none.
+ *   - return value: 0 = TE_OK; negative = TE_ERR_* below; positive = a hipError_t from the launch.
+ *   - `variant`: low byte TE_VARIANT_OURS (modules/layers_ours.py) or TE_VARIANT_LRP
+ *     (modules/layers_lrp.py); OR-in TE_IMPL_SIMPLE to force the simple (non-MFMA) device kernels,
+ *     which tests use as an on-device cross-check of the tiled kernels.
+ *   - safe_divide(a,b) = a / (b + 1e-9 [==0 -> 1e-9]) * (b != 0)     modules/layers_ours.py:10-13
+ */
+#ifndef TE_RELPROP_H
+#define TE_RELPROP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* te_stream_t; /* hipStream_t */
+
+enum {
+  TE_OK = 0,
+  TE_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, bad variant */
+  TE_ERR_WORKSPACE = -2,   /* ws == NULL or ws_bytes too small */
+  TE_ERR_UNSUPPORTED = -3, /* shape outside what the kernels implement */
+  TE_ERR_NO_DEVICE = -4    /* no gfx950 device visible */
+};
+
+enum { TE_VARIANT_OURS = 0, TE_VARIANT_LRP = 1, TE_IMPL_SIMPLE = 0x100 };
+
+enum { TE_ROLLOUT_NORMALISE = 1, TE_ROLLOUT_CLS_FIXUP = 2 };
+
+/* library version (major*10000 + minor*100 + patch) and status strings */
+int te_version(void);
+const char* te_status_string(int status);
+/* 0 if device 0..n-1 contains a gfx950 agent usable by this library, TE_ERR_NO_DEVICE otherwise */
+int te_device_check(void);
+
+/* ---- a3  Linear.relprop -------------------------------------------------------------------
+ * replaces modules/layers_ours.py:207-230 (ours) and modules/layers_lrp.py:188-211 (lrp), and the
+ * BERT copies BERT_explainability/modules/layers_ours.py:219-242.
+ *   R [T,out_f], X [T,in_f], W [out_f,in_f] -> out [T,in_f]          (T = B*N rows, bias unused)
+ *   ours: Z = X+ W+^T + X- W-^T ; S = sd(R,Z) ; act = X+ .(S W+) + X- .(S W-)
+ *   lrp : S1 = sd(R, X+ W+^T) ; S2 = sd(R, X- W-^T) ; act = X+ .(S1 W+) + X- .(S2 W-)
+ *   out = alpha*act - (alpha-1)*inh, inh = the same with W+ and W- exchanged (skipped at alpha==1).
+ */
+size_t te_linear_relprop_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f, int variant);
+int te_linear_relprop_f32(const float* R, const float* X, const float* W, float* out,
+                          int64_t T, int64_t in_f, int64_t out_f, float alpha, int variant,
+                          void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* The two kernels of te_linear_relprop_f32 (variant ours, alpha = 1, in_f and out_f multiples of 4,
+ * 16-byte aligned pointers) as separate launches:
+ *   zpass: S [T,out_f] = sd(R, X+ W+^T + X- W-^T)      (layers_ours.py:216-219)
+ *   cpass: out [T,in_f] = X+ .(S W+) + X- .(S W-)       (layers_ours.py:220-223,225)
+ * Callers that want to time or overlap a single kernel launch use these; results are identical to
+ * the composed call. */
+int te_linear_zpass_f32(const float* R, const float* X, const float* W, float* S,
+                        int64_t T, int64_t in_f, int64_t out_f, te_stream_t stream);
+int te_linear_cpass_f32(const float* S, const float* X, const float* W, float* out,
+                        int64_t T, int64_t in_f, int64_t out_f, te_stream_t stream);
+
+/* ---- a4  einsum / MatMul relprop (RelPropSimple) ---------------------------------------------
+ * replaces modules/layers_ours.py:48-60,122-127 and BERT_explainability/modules/layers_ours.py:89-91
+ * for the two products of self-attention.  Element (b,h,n,d) of a strided operand T lives at
+ * T + b*sb + h*sh + n*sn + d, so q/k/v can be read in place from the fused qkv activation
+ * [B,N,3*H*D] (ViT_LRP.py:135) or from separate [B,N,H*D] tensors (BERT.py:330-336), and the
+ * outputs can be written straight into the concatenated 'b n (qkv h d)' layout (ViT_LRP.py:175).
+ * attn / cam_attn / R_nn are contiguous [B,H,N,N].  Both outputs are multiplied by out_scale
+ * (callers pass 0.5: ViT_LRP.py:161-162,172-173; BERT.py:373-374,392-393).
+ *
+ * AV  (einsum 'bhij,bhjd->bhid'; BERT MatMul([probs, V])):
+ *   Z = attn v ; S = sd(R,Z) ; cam_attn = attn .(S v^T) ; cam_v = v .(attn^T S)
+ * QK  (einsum 'bhid,bhjd->bhij'; BERT MatMul([Q, K^T])), Z uses the UNSCALED q k^T:
+ *   Z = q k^T ; S = sd(R_nn,Z) ; cam_q = q .(S k) ; cam_k = k .(S^T q)
+ */
+size_t te_matmul_relprop_av_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t D);
+int te_matmul_relprop_av_f32(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn,
+                             const float* attn,
+                             const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                             float* cam_attn,
+                             float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
+                             int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
+                             void* ws, size_t ws_bytes, te_stream_t stream);
+size_t te_matmul_relprop_qk_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t D);
+int te_matmul_relprop_qk_f32(const float* R_nn,
+                             const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                             const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                             float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
+                             float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
+                             int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
+                             void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* ---- a5  Add.relprop ---------------------------------------------------------------------------
+ * replaces modules/layers_ours.py:97-120 (ours: three per-sample sums + rescale) and
+ * modules/layers_lrp.py:98-100 (lrp: plain RelPropSimple).  R, X0, out0, out1 are [B,n]; X1 is [B,n]
+ * (x1_batch_stride = n) or shared by all samples (x1_batch_stride = 0, e.g. pos_embed).
+ *   S = sd(R, X0+X1) ; a = X0.S ; b = X1.S ;
+ *   ours: a *= sd(sd(|Sa|,|Sa|+|Sb|)*SR, Sa) ; b *= sd(sd(|Sb|,|Sa|+|Sb|)*SR, Sb)   (per sample)
+ */
+size_t te_add_relprop_workspace_bytes(int64_t B, int64_t n);
+int te_add_relprop_f32(const float* R, const float* X0, const float* X1, float* out0, float* out1,
+                       int64_t B, int64_t n, int64_t x1_batch_stride, int variant,
+                       void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* Broadcast-operand Add of BERT self-attention (BERT.py:342,386-388): X0 = scaled scores
+ * [B,H,N,N], X1 = extended mask [B,1,1,N] given as mask [B,N].  out0 [B,H,N,N] (relevance of the
+ * scores); out1 [B,N] (relevance of the mask, discarded by the reference) may be NULL.
+ *   S = sd(R, X0 + mask_j) ; a = X0.S ; C1_j = sum_{h,i} S ; b_j = mask_j C1_j ; rescale as above.
+ */
+size_t te_add_bcast_relprop_workspace_bytes(int64_t B, int64_t H, int64_t N);
+int te_add_bcast_relprop_f32(const float* R, const float* X0, const float* mask, float* out0,
+                             float* out1, int64_t B, int64_t H, int64_t N, int variant,
+                             void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* ---- a6  Clone.relprop --------------------------------------------------------------------------
+ * replaces modules/layers_ours.py:151-169.  out = X .(sd(R0,X) + sd(R1,X) [+ sd(R2,X)]); R2 may be
+ * NULL (num = 2: ViT_LRP.py:194-196, BERT.py:247,527) or not (num = 3: BERT.py:407). n elements. */
+int te_clone_relprop_f32(const float* R0, const float* R1, const float* R2, const float* X,
+                         float* out, int64_t n, te_stream_t stream);
+
+/* ---- a7  IndexSelect.relprop ----------------------------------------------------------------------
+ * replaces modules/layers_ours.py:129-147 for dim=1, one index (ViT_LRP.py:319,329; BERT.py:170,189).
+ * R [B,C], X [B,N,C] -> out [B,N,C]: row `index` = X_row . sd(R, X_row), all other rows zero. */
+int te_index_select_relprop_f32(const float* R, const float* X, float* out,
+                                int64_t B, int64_t N, int64_t C, int64_t index, te_stream_t stream);
+
+/* ---- a10  gradient x relevance, clamp, head mean ------------------------------------------------
+ * replaces ViT_LRP.py:359-366 and ExplanationGenerator.py:49-56 (per sample):
+ * grad, cam [B,H,N,N] -> out [B,N,N] = (sum_h max(grad*cam, 0)) / H. */
+int te_gradcam_headmean_f32(const float* grad, const float* cam, float* out,
+                            int64_t B, int64_t H, int64_t N, te_stream_t stream);
+
+/* ---- a11  rollout ---------------------------------------------------------------------------------
+ * replaces compute_rollout_attention, ViT_LRP.py:38-49 (flags = 0) and ExplanationGenerator.py:7-18
+ * (TE_ROLLOUT_NORMALISE), plus the CLS fix-up ExplanationGenerator.py:58 (TE_ROLLOUT_CLS_FIXUP:
+ * joint[b,0,0] = min_j joint[b,0,j]).  cams [L,B,N,N] -> joint [B,N,N]:
+ *   M_l = cams_l + I (/ rowsum) ; J = M_start ; J = M_i J for i = start+1 .. L-1. */
+size_t te_rollout_workspace_bytes(int64_t L, int64_t B, int64_t N);
+int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
+                   int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TE_RELPROP_H */

@@ -1,0 +1,82 @@
+"""TEST-ONLY stand-in for transformer_explainability_amd.ops backed by the CPU oracle.
+
+Lets the `-m "not gpu"` suite exercise the host logic (rule classes, model relprop composition,
+stride/view plumbing, generators, sharding) on a machine without a GPU.  The product never uses this.
+"""
+import contextlib
+
+import torch
+
+from oracle import relprop_oracle as O
+
+
+def linear_relprop(R, X, W, alpha=1.0, variant="ours"):
+    return O.linear_relprop(R, X, W, alpha=alpha, variant=variant)
+
+
+def matmul_relprop_av(R, attn, v, out_scale=1.0, cam_v_out=None, variant="ours"):
+    c_attn, c_v = O.einsum_av_relprop(R, attn, v)
+    c_attn = c_attn * out_scale
+    c_v = c_v * out_scale
+    if cam_v_out is not None:
+        cam_v_out.copy_(c_v)
+        c_v = cam_v_out
+    return c_attn.contiguous(), c_v
+
+
+def matmul_relprop_qk(R, q, k, out_scale=1.0, cam_q_out=None, cam_k_out=None, variant="ours"):
+    c_q, c_k = O.einsum_qk_relprop(R, q, k)
+    c_q = c_q * out_scale
+    c_k = c_k * out_scale
+    if cam_q_out is not None:
+        cam_q_out.copy_(c_q)
+        c_q = cam_q_out
+    if cam_k_out is not None:
+        cam_k_out.copy_(c_k)
+        c_k = cam_k_out
+    return c_q, c_k
+
+
+def add_relprop(R, X0, X1, variant="ours"):
+    return O.add_relprop(R, X0, X1, variant)
+
+
+def clone_relprop(Rs, X):
+    return O.clone_relprop(list(Rs), X)
+
+
+def index_select_relprop(R, X, index):
+    return O.index_select_relprop(R.reshape(X.shape[0], 1, X.shape[2]), X, 1, index)
+
+
+def gradcam_headmean(grad, cam, out=None):
+    r = O.gradcam_headmean(grad, cam)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def rollout(cams, start_layer=0, normalise=False, cls_fixup=False):
+    joint = O.rollout(list(cams), start_layer, normalise=normalise).clone()
+    if cls_fixup:
+        joint[:, 0, 0] = joint[:, 0].min(dim=-1).values
+    return joint
+
+
+_NAMES = ["linear_relprop", "matmul_relprop_av", "matmul_relprop_qk", "add_relprop", "clone_relprop",
+          "index_select_relprop", "gradcam_headmean", "rollout"]
+
+
+@contextlib.contextmanager
+def oracle_ops():
+    """Temporarily route transformer_explainability_amd.ops.* to the oracle (CPU tensors)."""
+    from transformer_explainability_amd import ops
+    saved = {n: getattr(ops, n) for n in _NAMES}
+    try:
+        for n in _NAMES:
+            setattr(ops, n, globals()[n])
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)

@@ -1,0 +1,71 @@
+"""C-ABI surface checks that need no GPU: the library is built, loads through ctypes, exports every
+symbol include/te_relprop.h declares, and the host-side workspace queries / argument validation work."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "te_relprop.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    from transformer_explainability_amd import _lib
+    return _lib.load()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(te_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in te_relprop.h but not exported by libte_relprop.so"
+
+
+def test_binding_covers_header():
+    from transformer_explainability_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_version_and_status(lib):
+    assert lib.te_version() >= 100
+    assert lib.te_status_string(0) == b"ok"
+    assert b"workspace" in lib.te_status_string(-2)
+
+
+def test_workspace_queries(lib):
+    T, i, o = 12608, 768, 3072
+    assert lib.te_linear_relprop_workspace_bytes(T, i, o, 0) >= T * o * 4
+    assert lib.te_linear_relprop_workspace_bytes(T, i, o, 1) >= 2 * T * o * 4
+    assert lib.te_matmul_relprop_av_workspace_bytes(64, 12, 197, 64) >= 64 * 12 * 197 * 64 * 4
+    assert lib.te_matmul_relprop_qk_workspace_bytes(64, 12, 197, 64) >= 64 * 12 * 197 * 197 * 4
+    assert lib.te_add_relprop_workspace_bytes(64, 197 * 768) > 0
+    assert lib.te_add_bcast_relprop_workspace_bytes(32, 12, 512) > 0
+    assert lib.te_rollout_workspace_bytes(12, 64, 197) >= 13 * 64 * 197 * 197 * 4
+    assert lib.te_linear_relprop_workspace_bytes(0, 1, 1, 0) == 0
+
+
+def test_argument_validation_without_device(lib):
+    # null pointers / bad sizes are rejected on the host before any HIP call
+    assert lib.te_clone_relprop_f32(None, None, None, None, None, 16, None) == -1
+    assert lib.te_linear_relprop_f32(None, None, None, None, 1, 4, 4, 1.0, 0, None, 0, None) == -1
+    assert lib.te_rollout_f32(None, 1, 0, 1, 4, 0, None, None, 0, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from transformer_explainability_amd import ops, TeError
+    x = torch.zeros(2, 8)
+    with pytest.raises(TeError):
+        ops.clone_relprop([x, x], x)

@@ -1,0 +1,275 @@
+"""`-m gpu`: every relprop rule, HIP kernels through the C ABI vs the CPU oracle on the same seeded
+inputs, vs the golden fixtures produced by the reference, for the tiled (MFMA) AND the simple device
+kernels.  Tolerances: element-wise rules are evaluated op for op like the reference (exact or 1 ulp-
+level); GEMM-carrying rules differ only by fp32 summation order (relative 2e-5 of the tensor max)."""
+import pytest
+import torch
+
+from gpu_util import check, dev, record, rnd
+from oracle import relprop_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _impl(request):
+    from transformer_explainability_amd import ops
+    simple = getattr(request, "param", None)
+    yield
+    ops.FORCE_SIMPLE = False
+
+
+def set_impl(simple):
+    from transformer_explainability_amd import ops
+    ops.FORCE_SIMPLE = bool(simple)
+
+
+def test_single_hip_runtime():
+    from transformer_explainability_amd import _lib
+    _lib.require_device()
+    rts = _lib.hip_runtimes_loaded()
+    record("hip_runtimes", runtimes=rts)
+    assert len(rts) == 1, rts
+
+
+# ------------------------------------------------------------------------------------------ clone
+@pytest.mark.parametrize("num", [2, 3])
+@pytest.mark.parametrize("shape", [(2, 5, 12), (3, 197, 768), (1, 7, 3)])
+def test_clone(num, shape):
+    from transformer_explainability_amd import ops
+    X = rnd(shape, 1)
+    X.view(-1)[0] = 0.0
+    Rs = [rnd(shape, 10 + i, 0.01) for i in range(num)]
+    got = ops.clone_relprop([r.to(dev()) for r in Rs], X.to(dev()))
+    check(f"clone{num}{shape}", got, O.clone_relprop(Rs, X), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ add
+@pytest.mark.parametrize("variant", ["ours", "lrp"])
+@pytest.mark.parametrize("shape", [(1, 9, 16), (3, 197, 768), (2, 5, 3), (64, 33, 64)])
+def test_add(variant, shape):
+    from transformer_explainability_amd import ops
+    X0, X1, R = rnd(shape, 2), rnd(shape, 3), rnd(shape, 4, 0.01)
+    X0.view(-1)[0] = 0.0
+    X1.view(-1)[0] = 0.0
+    a, b = ops.add_relprop(R.to(dev()), X0.to(dev()), X1.to(dev()), variant=variant)
+    ra, rb = O.add_relprop(R, X0, X1, variant)
+    # the per-sample sums are accumulated in fp64 here and pairwise in fp32 by torch: ~1e-6 relative
+    check(f"add_{variant}{shape}.a", a, ra, 2e-5)
+    check(f"add_{variant}{shape}.b", b, rb, 2e-5)
+
+
+def test_add_batch_independent_and_shared_x1():
+    from transformer_explainability_amd import ops
+    shape = (4, 50, 64)
+    X0, X1, R = rnd(shape, 5).to(dev()), rnd(shape, 6).to(dev()), rnd(shape, 7, 0.01).to(dev())
+    a, b = ops.add_relprop(R, X0, X1)
+    for i in range(4):
+        ai, bi = ops.add_relprop(R[i:i + 1], X0[i:i + 1], X1[i:i + 1])
+        assert torch.equal(ai, a[i:i + 1]) and torch.equal(bi, b[i:i + 1])
+    # shared (batch-less) second operand, e.g. pos_embed
+    a2, b2 = ops.add_relprop(R, X0, X1[:1])
+    ra, rb = O.add_relprop(R.cpu(), X0.cpu(), X1[:1].cpu())
+    check("add_shared_x1.a", a2, ra, 2e-5)
+    check("add_shared_x1.b", b2, rb, 2e-5)
+
+
+@pytest.mark.parametrize("B,H,N", [(1, 3, 7), (2, 12, 128), (3, 4, 300)])
+def test_add_bcast_mask(B, H, N):
+    from transformer_explainability_amd import ops
+    X0 = rnd((B, H, N, N), 8)
+    R = rnd((B, H, N, N), 9, 0.01)
+    mask = torch.zeros(B, 1, 1, N)
+    mask[..., N - max(1, N // 5):] = -10000.0
+    R[..., N - max(1, N // 5):] = 0.0          # relevance of masked keys is zero in practice (probs = 0)
+    a, b = ops.add_relprop(R.to(dev()), X0.to(dev()), mask.to(dev()))
+    ra, rb = O.add_relprop(R, X0, mask)
+    check(f"add_bcast({B},{H},{N}).a", a, ra, 2e-5)
+    assert b.shape == (B, 1, 1, N)
+
+
+def test_add_bcast_nonzero_mask_relevance():
+    from transformer_explainability_amd import ops
+    B, H, N = 2, 3, 9
+    X0, R = rnd((B, H, N, N), 18), rnd((B, H, N, N), 19, 0.01)
+    mask = rnd((B, 1, 1, N), 20)
+    a, b = ops.add_relprop(R.to(dev()), X0.to(dev()), mask.to(dev()))
+    ra, rb = O.add_relprop(R, X0, mask)
+    check("add_bcast_dense.a", a, ra, 5e-5)
+    check("add_bcast_dense.b", b, rb, 5e-5)
+
+
+# ------------------------------------------------------------------------------------------ index select
+def test_index_select():
+    from transformer_explainability_amd import ops
+    X, R = rnd((3, 197, 768), 11), rnd((3, 1, 768), 12, 0.01)
+    got = ops.index_select_relprop(R.to(dev()), X.to(dev()), 0)
+    check("index_select", got, O.index_select_relprop(R, X, 1, 0), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ head mean
+@pytest.mark.parametrize("B,H,N", [(2, 12, 197), (1, 4, 17), (2, 3, 64)])
+def test_headmean(B, H, N):
+    from transformer_explainability_amd import ops
+    g, c = rnd((B, H, N, N), 13), rnd((B, H, N, N), 14, 0.01)
+    got = ops.gradcam_headmean(g.to(dev()), c.to(dev()))
+    check(f"headmean({B},{H},{N})", got, O.gradcam_headmean(g, c), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ linear
+LINEAR_SHAPES = [(10, 24, 40), (300, 768, 2304), (197, 3072, 768), (64, 768, 1000), (7, 10, 2), (130, 64, 192),
+                 (257, 1024, 4096)]
+
+
+@pytest.mark.parametrize("simple", [False, True], ids=["tiled", "simple"])
+@pytest.mark.parametrize("variant", ["ours", "lrp"])
+@pytest.mark.parametrize("T,in_f,out_f", LINEAR_SHAPES)
+def test_linear(simple, variant, T, in_f, out_f):
+    from transformer_explainability_amd import ops
+    set_impl(simple)
+    X, W, R = rnd((T, in_f), 21), rnd((out_f, in_f), 22, 0.05), rnd((T, out_f), 23, 0.01)
+    X[0, :3] = 0.0
+    got = ops.linear_relprop(R.to(dev()), X.to(dev()), W.to(dev()), alpha=1.0, variant=variant)
+    ref = O.linear_relprop(R, X, W, 1.0, variant)
+    check(f"linear_{variant}_{'simple' if simple else 'tiled'}({T},{in_f},{out_f})", got, ref, 2e-5)
+
+
+@pytest.mark.parametrize("simple", [False, True], ids=["tiled", "simple"])
+@pytest.mark.parametrize("variant", ["ours", "lrp"])
+def test_linear_alpha2(simple, variant):
+    from transformer_explainability_amd import ops
+    set_impl(simple)
+    T, in_f, out_f = 70, 96, 160
+    X, W, R = rnd((2, 35, in_f), 24), rnd((out_f, in_f), 25, 0.05), rnd((2, 35, out_f), 26, 0.01)
+    got = ops.linear_relprop(R.to(dev()), X.to(dev()), W.to(dev()), alpha=2.0, variant=variant)
+    check(f"linear_alpha2_{variant}_{simple}", got, O.linear_relprop(R, X, W, 2.0, variant), 5e-5)
+    assert got.shape == (2, 35, in_f)
+
+
+def test_linear_rows_independent_and_homogeneous():
+    """size-independent properties at the full ViT-B width: a row's result does not depend on which
+    other rows share its tile (bitwise), and relprop(2R) == 2 relprop(R) bitwise."""
+    from transformer_explainability_amd import ops
+    T, in_f, out_f = 394, 768, 3072
+    X, W, R = rnd((T, in_f), 27).to(dev()), rnd((out_f, in_f), 28, 0.05).to(dev()), rnd((T, out_f), 29, 0.01).to(dev())
+    full = ops.linear_relprop(R, X, W)
+    part = ops.linear_relprop(R[100:231].contiguous(), X[100:231].contiguous(), W)
+    assert torch.equal(full[100:231], part)
+    twice = ops.linear_relprop(2 * R, X, W)
+    assert torch.equal(twice, 2 * full)
+    # conservation: sum_i out[t,i] == sum_j R[t,j] (all Z != 0 here)
+    cons = (full.double().sum(-1) - R.double().sum(-1)).abs().max() / R.double().abs().sum(-1).max()
+    record("linear_conservation", rel=float(cons))
+    assert float(cons) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ attention rules
+@pytest.mark.parametrize("simple", [False, True], ids=["tiled", "simple"])
+@pytest.mark.parametrize("B,H,N,D", [(2, 3, 7, 8), (2, 12, 197, 64), (1, 4, 130, 64), (1, 2, 577, 64)])
+def test_attention_rules_fused_qkv_layout(simple, B, H, N, D):
+    """q/k/v read in place from the fused qkv activation [B,N,3HD]; outputs written in place into the
+    'b n (qkv h d)' relevance buffer (strided views)."""
+    from transformer_explainability_amd import ops
+    set_impl(simple)
+    C = H * D
+    qkv = rnd((B, N, 3 * C), 31)
+    v5 = qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    q, k, v = v5[0], v5[1], v5[2]
+    attn = torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1).contiguous()
+    Rav = rnd((B, N, C), 32, 0.01)
+    r_heads = Rav.view(B, N, H, D).permute(0, 2, 1, 3)
+    ref_attn, ref_v = O.einsum_av_relprop(r_heads, attn, v)
+    ref_q, ref_k = O.einsum_qk_relprop(ref_attn * 0.5, q, k)
+
+    d = dev()
+    qkv_d = qkv.to(d)
+    v5d = qkv_d.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    cam_qkv = torch.full((B, N, 3 * C), float("nan"), device=d)
+    slots = cam_qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    cam1, cam_v = ops.matmul_relprop_av(Rav.to(d).view(B, N, H, D).permute(0, 2, 1, 3), attn.to(d), v5d[2],
+                                        out_scale=0.5, cam_v_out=slots[2])
+    ops.matmul_relprop_qk(cam1, v5d[0], v5d[1], out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1])
+    tag = f"({B},{H},{N},{D}){'simple' if simple else 'tiled'}"
+    check("av.cam_attn" + tag, cam1, ref_attn * 0.5, 3e-5)
+    check("av.cam_v" + tag, slots[2], ref_v * 0.5, 3e-5)
+    check("qk.cam_q" + tag, slots[0], ref_q * 0.5, 3e-5)
+    check("qk.cam_k" + tag, slots[1], ref_k * 0.5, 3e-5)
+    assert not torch.isnan(cam_qkv).any()       # every slot of the fused buffer was written
+
+
+# ------------------------------------------------------------------------------------------ rollout
+@pytest.mark.parametrize("L,B,N,start", [(4, 2, 50, 0), (12, 2, 197, 1), (3, 1, 197, 2), (5, 3, 64, 4)])
+@pytest.mark.parametrize("normalise", [False, True])
+def test_rollout(L, B, N, start, normalise):
+    from transformer_explainability_amd import ops
+    cams = rnd((L, B, N, N), 41).abs() * 0.01
+    got = ops.rollout(cams.to(dev()), start_layer=start, normalise=normalise)
+    ref = O.rollout(list(cams), start, normalise=normalise)
+    check(f"rollout({L},{B},{N},{start},{normalise})", got, ref, 1e-5)
+    got2 = ops.rollout(cams.to(dev()), start_layer=start, normalise=normalise, cls_fixup=True)
+    ref2 = ref.clone()
+    ref2[:, 0, 0] = ref[:, 0].min(dim=-1).values
+    check(f"rollout_fixup({L},{B},{N},{start},{normalise})", got2, ref2, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------ golden (reference outputs)
+def test_golden_rules(golden_rules):
+    from transformer_explainability_amd import ops
+    g = golden_rules
+    d = dev()
+    for variant in ("ours", "lrp"):
+        for alpha in (1, 2):
+            got = ops.linear_relprop(g[f"linear_{variant}.R"].to(d), g[f"linear_{variant}.X"].to(d),
+                                     g[f"linear_{variant}.W"].to(d), alpha=alpha, variant=variant)
+            check(f"golden.linear_{variant}_a{alpha}", got, g[f"linear_{variant}.out_a{alpha}"], 2e-5)
+        a, b = ops.add_relprop(g[f"add_{variant}.R"].to(d), g[f"add_{variant}.X0"].to(d), g[f"add_{variant}.X1"].to(d),
+                               variant=variant)
+        check(f"golden.add_{variant}.a", a, g[f"add_{variant}.out0"], 2e-5)
+        check(f"golden.add_{variant}.b", b, g[f"add_{variant}.out1"], 2e-5)
+    o0, o1 = ops.matmul_relprop_av(g["av.R"].to(d), g["av.attn"].to(d), g["av.v"].to(d))
+    check("golden.av.out0", o0, g["av.out0"], 2e-5)
+    check("golden.av.out1", o1, g["av.out1"], 2e-5)
+    o0, o1 = ops.matmul_relprop_qk(g["qk.R"].to(d), g["qk.q"].to(d), g["qk.k"].to(d))
+    check("golden.qk.out0", o0, g["qk.out0"], 2e-5)
+    check("golden.qk.out1", o1, g["qk.out1"], 2e-5)
+    a, b = ops.add_relprop(g["add_mask.R"].to(d), g["add_mask.X0"].to(d), g["add_mask.X1"].to(d))
+    check("golden.add_mask.a", a, g["add_mask.out0"], 2e-5)
+    for num in (2, 3):
+        got = ops.clone_relprop([g[f"clone{num}.R{i}"].to(d) for i in range(num)], g[f"clone{num}.X"].to(d))
+        check(f"golden.clone{num}", got, g[f"clone{num}.out"], 1e-6)
+    got = ops.index_select_relprop(g["index_select.R"].to(d), g["index_select.X"].to(d), 0)
+    check("golden.index_select", got, g["index_select.out"], 1e-6)
+
+
+def test_rule_modules_match_reference_api(golden_rules):
+    """The rule CLASSES (forward hook state + relprop(R, alpha)) reproduce the reference's outputs."""
+    from transformer_explainability_amd import rules, rules_lrp
+    g = golden_rules
+    d = dev()
+    for variant, mod in (("ours", rules), ("lrp", rules_lrp)):
+        lin = mod.Linear(24, 40).to(d)
+        with torch.no_grad():
+            lin.weight.copy_(g[f"linear_{variant}.W"])
+        lin(g[f"linear_{variant}.X"].to(d))
+        check(f"module.linear_{variant}", lin.relprop(g[f"linear_{variant}.R"].to(d), 1),
+              g[f"linear_{variant}.out_a1"], 2e-5)
+        add = mod.Add()
+        add([g[f"add_{variant}.X0"].to(d), g[f"add_{variant}.X1"].to(d)])
+        a, b = add.relprop(g[f"add_{variant}.R"].to(d), 1)
+        check(f"module.add_{variant}.a", a, g[f"add_{variant}.out0"], 2e-5)
+    e2 = rules.einsum('bhij,bhjd->bhid')
+    e2([g["av.attn"].to(d), g["av.v"].to(d)])
+    o0, o1 = e2.relprop(g["av.R"].to(d), 1)
+    check("module.einsum_av.0", o0, g["av.out0"], 2e-5)
+    check("module.einsum_av.1", o1, g["av.out1"], 2e-5)
+    mm = rules.MatMul()
+    mm([g["qk.q"].to(d), g["qk.k"].to(d).transpose(-1, -2)])
+    o0, o1 = mm.relprop(g["qk.R"].to(d), 1)
+    check("module.matmul_qkT.0", o0, g["matmul_qkT.out0"], 2e-5)
+    check("module.matmul_qkT.1", o1, g["matmul_qkT.out1"], 2e-5)
+    cl = rules.Clone()
+    cl(g["clone3.X"].to(d), 3)
+    check("module.clone3", cl.relprop([g[f"clone3.R{i}"].to(d) for i in range(3)], 1), g["clone3.out"], 1e-6)
+    isel = rules.IndexSelect()
+    isel(g["index_select.X"].to(d), 1, torch.tensor(0, device=d))
+    check("module.index_select", isel.relprop(g["index_select.R"].to(d), 1), g["index_select.out"], 1e-6)

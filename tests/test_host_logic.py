@@ -1,0 +1,138 @@
+"""Host-logic tests on CPU: the model / rule / generator plumbing of the package, with the device ops
+swapped for the oracle (tests/oracle_backend.py).  Checks against the golden fixtures produced by the
+reference, so they also pin our forward pass and state_dict layout."""
+import pytest
+import torch
+
+from conftest import unflatten_cache
+from oracle_backend import oracle_ops
+
+
+def _state(g, prefix="state."):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def tiny_vit(golden_vit_tiny):
+    from transformer_explainability_amd import vit
+    m = vit.VisionTransformer(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10,
+                              qkv_bias=True).eval()
+    missing = m.load_state_dict(_state(golden_vit_tiny), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+def test_vit_forward_matches_reference(tiny_vit, golden_vit_tiny):
+    g = golden_vit_tiny
+    assert _rel(tiny_vit(g["x"]).detach(), g["ours.logits"]) < 1e-5
+
+
+@pytest.mark.parametrize("start_layer", [0, 1])
+def test_vit_generate_lrp_batched(tiny_vit, golden_vit_tiny, start_layer):
+    from transformer_explainability_amd.generators import LRP
+    g = golden_vit_tiny
+    with oracle_ops():
+        out = LRP(tiny_vit).generate_LRP(g["x"], method="transformer_attribution", start_layer=start_layer)
+    assert out.shape == (2, 16)
+    assert _rel(out.detach(), g[f"ours.map_sl{start_layer}"]) < 1e-4
+    for i, blk in enumerate(tiny_vit.blocks):
+        assert _rel(blk.attn.get_attn_cam()[:1], g[f"ours.attn_cam.{i}"]) < 1e-4
+        assert _rel(blk.attn.get_v_cam()[:1], g[f"ours.v_cam.{i}"]) < 1e-4
+
+
+def test_vit_explicit_index_and_other_methods(tiny_vit, golden_vit_tiny):
+    from transformer_explainability_amd.generators import LRP
+    g = golden_vit_tiny
+    with oracle_ops():
+        lrp = LRP(tiny_vit)
+        out = lrp.generate_LRP(g["x"], index=3, start_layer=0)
+        assert _rel(out.detach(), g["ours.map_sl0_idx3"]) < 1e-4
+        out = lrp.generate_LRP(g["x"], method="rollout", start_layer=0)
+        assert _rel(out.detach(), g["ours.rollout_sl0"]) < 1e-4
+        out = lrp.generate_LRP(g["x"][:1], method="last_layer")
+        assert _rel(out.detach(), g["ours.last_layer"]) < 1e-4
+        assert lrp.generate_LRP(g["x"][:1], method="no_such_method") is None
+
+
+def test_vit_lrp_variant(golden_vit_tiny):
+    from transformer_explainability_amd import rules_lrp, vit
+    from transformer_explainability_amd.generators import LRP
+    g = golden_vit_tiny
+    ns = vit.make_vit_module(rules_lrp)
+    m = ns["VisionTransformer"](img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10,
+                                qkv_bias=True).eval()
+    m.load_state_dict(_state(g))
+    with oracle_ops():
+        out = LRP(m).generate_LRP(g["x"], method="grad", start_layer=0)
+    assert _rel(out.detach(), g["lrp.map_sl0"]) < 1e-4
+
+
+@pytest.fixture(scope="module")
+def tiny_bert(golden_bert_tiny):
+    from transformer_explainability_amd import bert
+    cfg = bert.BertConfigLite(vocab_size=100, hidden_size=64, num_hidden_layers=3, num_attention_heads=4,
+                              intermediate_size=128, max_position_embeddings=40, num_labels=2)
+    m = bert.BertForSequenceClassification(cfg).eval()
+    m.load_state_dict(_state(golden_bert_tiny), strict=True)
+    return m
+
+
+@pytest.mark.parametrize("start_layer", [0, 2])
+def test_bert_generate_lrp_batched(tiny_bert, golden_bert_tiny, start_layer):
+    from transformer_explainability_amd.generators import Generator
+    g = golden_bert_tiny
+    ids, mask = g["input_ids"].long(), g["attention_mask"]
+    assert _rel(tiny_bert(input_ids=ids, attention_mask=mask)[0].detach(), g["logits"]) < 1e-5
+    with oracle_ops():
+        out = Generator(tiny_bert).generate_LRP(input_ids=ids, attention_mask=mask, start_layer=start_layer)
+    assert out.shape == (2, 24)
+    assert _rel(out.detach(), g[f"map_sl{start_layer}"]) < 1e-4
+    for i, lay in enumerate(tiny_bert.bert.encoder.layer):
+        assert _rel(lay.attention.self.get_attn_cam()[:1], g[f"attn_cam.{i}"]) < 1e-4
+
+
+def test_bert_full_relprop_conservation(tiny_bert, golden_bert_tiny):
+    g = golden_bert_tiny
+    ids, mask = g["input_ids"][:1].long(), g["attention_mask"][:1]
+    logits = tiny_bert(input_ids=ids, attention_mask=mask)[0]
+    oh = torch.zeros_like(logits)
+    oh[0, logits.argmax(-1)] = 1
+    with oracle_ops():
+        cam = tiny_bert.relprop(oh, alpha=1)
+    assert _rel(cam.detach(), g["cam_tokens"]) < 1e-4
+    assert abs(float(cam.double().sum()) - 1.0) < 1e-4
+
+
+def test_dropin_import_paths(golden_vit_tiny):
+    """The reference's import paths resolve to this implementation."""
+    import importlib
+    import sys
+    import transformer_explainability_amd as te
+    d = te.install_dropin()
+    try:
+        for name in ("modules.layers_ours", "modules.layers_lrp", "baselines.ViT.ViT_LRP",
+                     "baselines.ViT.ViT_orig_LRP", "baselines.ViT.ViT_explanation_generator",
+                     "BERT_explainability.modules.layers_ours", "BERT_explainability.modules.layers_lrp",
+                     "BERT_explainability.modules.BERT.BERT", "BERT_explainability.modules.BERT.BERT_orig_lrp",
+                     "BERT_explainability.modules.BERT.BertForSequenceClassification",
+                     "BERT_explainability.modules.BERT.BERT_cls_lrp",
+                     "BERT_explainability.modules.BERT.ExplanationGenerator"):
+            mod = importlib.import_module(name)
+            assert mod.__file__.startswith(d), (name, mod.__file__)
+        lo = importlib.import_module("modules.layers_ours")
+        for cls in ("Linear", "Add", "Clone", "einsum", "IndexSelect", "LayerNorm", "GELU", "Softmax", "Dropout",
+                    "Conv2d", "safe_divide", "forward_hook"):
+            assert hasattr(lo, cls)
+        V = importlib.import_module("baselines.ViT.ViT_LRP")
+        m = V.vit_base_patch16_224  # factory exists with the reference's name
+        G = importlib.import_module("baselines.ViT.ViT_explanation_generator")
+        assert hasattr(G.LRP, "generate_LRP")
+        assert callable(m)
+    finally:
+        sys.path.remove(d)
+        for k in [k for k in sys.modules if k.split(".")[0] in ("modules", "baselines", "BERT_explainability")]:
+            del sys.modules[k]

@@ -1,0 +1,33 @@
+"""transformer-explainability_amd: MI355X-native relevance propagation ("transformer_attribution")
+behind the API of hila-chefer/Transformer-Explainability.
+
+Importable as ``transformer_explainability_amd`` (see the alias module at the repo root; the
+directory name carries a hyphen).  Layout:
+
+  csrc/ + ../include/te_relprop.h   hand-written HIP kernels (gfx950) and the C ABI
+  _lib.py, ops.py                   ctypes binding, tensor-level wrappers (no CPU fallback)
+  rules.py, rules_lrp.py            rule classes = modules/layers_ours.py / layers_lrp.py of the reference
+  vit.py, bert.py                   LRP-instrumented models = baselines/ViT/ViT_LRP.py, BERT.py ... of the reference
+  generators.py                     LRP.generate_LRP / Generator.generate_LRP
+  dropin/                           the reference's import paths (modules.layers_ours, baselines.ViT.ViT_LRP, ...)
+  parallel.py                       one-process-per-GPU sharding + RCCL gather of the finished maps
+"""
+from . import _lib, ops, rules, rules_lrp  # noqa: F401
+from ._lib import TeError, LIB_PATH  # noqa: F401
+
+__version__ = "0.1.0"
+
+
+def library_path() -> str:
+    return LIB_PATH
+
+
+def install_dropin() -> str:
+    """Put the reference-compatible import paths (modules.*, baselines.*, BERT_explainability.*) on
+    sys.path so the reference's evaluation scripts import this implementation unchanged."""
+    import os
+    import sys
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return d

@@ -1,0 +1,30 @@
+// te_api.hip -- version / status / device probe of libte_relprop.
+#include "te_common.h"
+
+#include <string.h>
+
+extern "C" int te_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* te_status_string(int status) {
+  switch (status) {
+    case TE_OK: return "ok";
+    case TE_ERR_INVALID_ARG: return "invalid argument";
+    case TE_ERR_WORKSPACE: return "workspace missing, misaligned or too small";
+    case TE_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    case TE_ERR_NO_DEVICE: return "no gfx950 device visible";
+    default: break;
+  }
+  if (status > 0) return hipGetErrorString((hipError_t)status);
+  return "unknown status";
+}
+
+extern "C" int te_device_check(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TE_ERR_NO_DEVICE;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) != hipSuccess) continue;
+    if (strncmp(p.gcnArchName, "gfx950", 6) == 0) return TE_OK;
+  }
+  return TE_ERR_NO_DEVICE;
+}

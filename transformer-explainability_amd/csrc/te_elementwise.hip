@@ -1,0 +1,499 @@
+// te_elementwise.hip -- HBM-bound relprop rules for gfx950: Add (ours / lrp / broadcast mask), Clone,
+// IndexSelect, gradient x relevance head-mean.  All kernels stream 16 B per lane where alignment
+// allows, reduce per SAMPLE (batch = independent batch-1 problems) with fp64 accumulators in a fixed
+// order (bit-reproducible, no atomics), and evaluate safe_divide exactly like the reference.
+//
+// Build flags matter: -ffp-contract=off (the reference rounds every product and sum separately).
+#include "te_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// 16-byte vector access that only promises 4-byte alignment (gfx950 global loads/stores of
+// dwordx4 are legal at dword alignment); used where per-(b,h) bases are odd multiples of 4 B.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename V>
+__device__ __forceinline__ V ld(const float* p) { return *reinterpret_cast<const V*>(p); }
+template <typename V>
+__device__ __forceinline__ void st(float* p, V v) { *reinterpret_cast<V*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------------
+// Add.relprop (modules/layers_ours.py:97-120).  Pass 1: per-(sample, chunk) partial sums.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void add_sums_kernel(
+    const float* __restrict__ R, const float* __restrict__ X0, const float* __restrict__ X1,
+    double* __restrict__ partial, int64_t n, int64_t x1_bs, int64_t chunk) {
+  __shared__ double smem[3 * (kThreads / 64)];
+  const int64_t b = blockIdx.y;
+  const int64_t start = (int64_t)blockIdx.x * chunk;
+  const int64_t end = min(n, start + chunk);
+  const float* r = R + b * n;
+  const float* x0 = X0 + b * n;
+  const float* x1 = X1 + b * x1_bs;
+  double sa = 0.0, sb = 0.0, sr = 0.0;
+  for (int64_t i = start + (int64_t)threadIdx.x * VEC; i < end; i += (int64_t)kThreads * VEC) {
+    if constexpr (VEC == 4) {
+      const f32x4 rv = ld<f32x4>(r + i), av = ld<f32x4>(x0 + i), bv = ld<f32x4>(x1 + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = te_sd(rv[e], av[e] + bv[e]);
+        sa += (double)(av[e] * s);
+        sb += (double)(bv[e] * s);
+        sr += (double)rv[e];
+      }
+    } else {
+      const float rv = r[i], av = x0[i], bv = x1[i];
+      const float s = te_sd(rv, av + bv);
+      sa += (double)(av * s);
+      sb += (double)(bv * s);
+      sr += (double)rv;
+    }
+  }
+  te_block_sum3(sa, sb, sr, smem);
+  if (threadIdx.x == 0) {
+    double* p = partial + (b * gridDim.x + blockIdx.x) * 3;
+    p[0] = sa;
+    p[1] = sb;
+    p[2] = sr;
+  }
+}
+
+// The scalar tail of Add.relprop: a_fact / b_fact and the two rescale factors, in fp32 like the
+// reference's 0-d tensors (layers_ours.py:112-116).
+__device__ __forceinline__ void add_factors(double A, double Bs, double Rs, float& fa, float& fb) {
+  const float a_sum = (float)A, b_sum = (float)Bs, r_sum = (float)Rs;
+  const float a_abs = fabsf(a_sum), b_abs = fabsf(b_sum);
+  const float den = a_abs + b_abs;
+  const float a_fact = te_sd(a_abs, den) * r_sum;
+  const float b_fact = te_sd(b_abs, den) * r_sum;
+  fa = te_sd(a_fact, a_sum);
+  fb = te_sd(b_fact, b_sum);
+}
+
+// Pass 2 (ours) / the only pass (lrp): recompute a, b and apply the per-sample factors.
+template <int VEC, bool OURS>
+__global__ __launch_bounds__(kThreads) void add_apply_kernel(
+    const float* __restrict__ R, const float* __restrict__ X0, const float* __restrict__ X1,
+    float* __restrict__ out0, float* __restrict__ out1, const double* __restrict__ partial,
+    int64_t n, int64_t x1_bs, int64_t chunk) {
+  __shared__ float fac[2];
+  const int64_t b = blockIdx.y;
+  float fa = 1.0f, fb = 1.0f;
+  if constexpr (OURS) {
+    if (threadIdx.x < 64) {  // one wave folds the chunk partials of this sample in a fixed tree
+      const int nb = gridDim.x;
+      double sa = 0.0, sb = 0.0, sr = 0.0;
+      for (int p = threadIdx.x; p < nb; p += 64) {
+        const double* q = partial + (b * nb + p) * 3;
+        sa += q[0];
+        sb += q[1];
+        sr += q[2];
+      }
+      sa = te_wave_sum(sa);
+      sb = te_wave_sum(sb);
+      sr = te_wave_sum(sr);
+      if (threadIdx.x == 0) {
+        add_factors(sa, sb, sr, fa, fb);
+        fac[0] = fa;
+        fac[1] = fb;
+      }
+    }
+    __syncthreads();
+    fa = fac[0];
+    fb = fac[1];
+  }
+  const int64_t start = (int64_t)blockIdx.x * chunk;
+  const int64_t end = min(n, start + chunk);
+  const float* r = R + b * n;
+  const float* x0 = X0 + b * n;
+  const float* x1 = X1 + b * x1_bs;
+  float* o0 = out0 + b * n;
+  float* o1 = out1 + b * n;
+  for (int64_t i = start + (int64_t)threadIdx.x * VEC; i < end; i += (int64_t)kThreads * VEC) {
+    if constexpr (VEC == 4) {
+      const f32x4 rv = ld<f32x4>(r + i), av = ld<f32x4>(x0 + i), bv = ld<f32x4>(x1 + i);
+      f32x4 oa, ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = te_sd(rv[e], av[e] + bv[e]);
+        float a = av[e] * s, bb = bv[e] * s;
+        if constexpr (OURS) {
+          a = a * fa;
+          bb = bb * fb;
+        }
+        oa[e] = a;
+        ob[e] = bb;
+      }
+      st<f32x4>(o0 + i, oa);
+      st<f32x4>(o1 + i, ob);
+    } else {
+      const float rv = r[i], av = x0[i], bv = x1[i];
+      const float s = te_sd(rv, av + bv);
+      float a = av * s, bb = bv * s;
+      if constexpr (OURS) {
+        a = a * fa;
+        bb = bb * fb;
+      }
+      o0[i] = a;
+      o1[i] = bb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Broadcast-mask Add of BERT self-attention (BERT.py:342,386-388).  Rows are the H*N (h,i) pairs of a
+// sample, columns j index the key token / mask entry.  Each thread owns columns j = tid + 256*c.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxColsPerThread = 8;  // N <= 2048
+
+__global__ __launch_bounds__(kThreads) void addb_sums_kernel(
+    const float* __restrict__ R, const float* __restrict__ X0, const float* __restrict__ mask,
+    double* __restrict__ partial, int64_t rows, int64_t N, int64_t rows_per_block) {
+  __shared__ double smem[3 * (kThreads / 64)];
+  const int64_t b = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  const float* r = R + b * rows * N;
+  const float* x0 = X0 + b * rows * N;
+  const float* m = mask + b * N;
+  double csum[kMaxColsPerThread];
+  float mv[kMaxColsPerThread];
+#pragma unroll
+  for (int c = 0; c < kMaxColsPerThread; ++c) {
+    csum[c] = 0.0;
+    const int64_t j = threadIdx.x + (int64_t)c * kThreads;
+    mv[c] = (j < N) ? m[j] : 0.0f;
+  }
+  double sa = 0.0, sr = 0.0, dummy = 0.0;
+  for (int64_t row = r0; row < r1; ++row) {
+#pragma unroll
+    for (int c = 0; c < kMaxColsPerThread; ++c) {
+      const int64_t j = threadIdx.x + (int64_t)c * kThreads;
+      if (j < N) {
+        const float rv = r[row * N + j], av = x0[row * N + j];
+        const float s = te_sd(rv, av + mv[c]);
+        sa += (double)(av * s);
+        sr += (double)rv;
+        csum[c] += (double)s;
+      }
+    }
+  }
+  double* p = partial + (b * gridDim.x + blockIdx.x) * (N + 2);
+#pragma unroll
+  for (int c = 0; c < kMaxColsPerThread; ++c) {
+    const int64_t j = threadIdx.x + (int64_t)c * kThreads;
+    if (j < N) p[2 + j] = csum[c];
+  }
+  te_block_sum3(sa, sr, dummy, smem);
+  if (threadIdx.x == 0) {
+    p[0] = sa;
+    p[1] = sr;
+  }
+}
+
+// One block per sample: fold the partials, form b_j = mask_j * C1_j, the three sums and the factors.
+// fac[b] = {fa, fb}; bvec[b][j] = b_j (unscaled).
+__global__ __launch_bounds__(kThreads) void addb_finalize_kernel(
+    const double* __restrict__ partial, const float* __restrict__ mask, float* __restrict__ fac,
+    float* __restrict__ bvec, int64_t N, int nblk, int ours) {
+  __shared__ double smem[3 * (kThreads / 64)];
+  const int64_t b = blockIdx.x;
+  const double* base = partial + b * nblk * (N + 2);
+  double sb = 0.0, sa = 0.0, sr = 0.0;
+  for (int64_t j = threadIdx.x; j < N; j += kThreads) {
+    double c1 = 0.0;
+    for (int p = 0; p < nblk; ++p) c1 += base[(int64_t)p * (N + 2) + 2 + j];
+    const float bj = mask[b * N + j] * (float)c1;
+    bvec[b * N + j] = bj;
+    sb += (double)bj;
+  }
+  for (int p = threadIdx.x; p < nblk; p += kThreads) {
+    sa += base[(int64_t)p * (N + 2) + 0];
+    sr += base[(int64_t)p * (N + 2) + 1];
+  }
+  te_block_sum3(sa, sb, sr, smem);
+  if (threadIdx.x == 0) {
+    float fa = 1.0f, fb = 1.0f;
+    if (ours) add_factors(sa, sb, sr, fa, fb);
+    fac[b * 2 + 0] = fa;
+    fac[b * 2 + 1] = fb;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void addb_apply_kernel(
+    const float* __restrict__ R, const float* __restrict__ X0, const float* __restrict__ mask,
+    const float* __restrict__ fac, const float* __restrict__ bvec, float* __restrict__ out0,
+    float* __restrict__ out1, int64_t rows, int64_t N, int64_t rows_per_block) {
+  const int64_t b = blockIdx.y;
+  const float fa = fac[b * 2 + 0], fb = fac[b * 2 + 1];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  const float* r = R + b * rows * N;
+  const float* x0 = X0 + b * rows * N;
+  const float* m = mask + b * N;
+  float* o0 = out0 + b * rows * N;
+  if (out1 != nullptr && blockIdx.x == 0) {
+    for (int64_t j = threadIdx.x; j < N; j += kThreads) out1[b * N + j] = bvec[b * N + j] * fb;
+  }
+  float mv[kMaxColsPerThread];
+#pragma unroll
+  for (int c = 0; c < kMaxColsPerThread; ++c) {
+    const int64_t j = threadIdx.x + (int64_t)c * kThreads;
+    mv[c] = (j < N) ? m[j] : 0.0f;
+  }
+  for (int64_t row = r0; row < r1; ++row) {
+#pragma unroll
+    for (int c = 0; c < kMaxColsPerThread; ++c) {
+      const int64_t j = threadIdx.x + (int64_t)c * kThreads;
+      if (j < N) {
+        const float rv = r[row * N + j], av = x0[row * N + j];
+        const float s = te_sd(rv, av + mv[c]);
+        o0[row * N + j] = (av * s) * fa;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Clone.relprop (modules/layers_ours.py:151-169): out = X * (sd(R0,X) + sd(R1,X) [+ sd(R2,X)])
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int NUM>
+__global__ __launch_bounds__(kThreads) void clone_kernel(
+    const float* __restrict__ R0, const float* __restrict__ R1, const float* __restrict__ R2,
+    const float* __restrict__ X, float* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads * VEC;
+  for (int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * VEC; i < n; i += stride) {
+    if constexpr (VEC == 4) {
+      const f32x4 x = ld<f32x4>(X + i), a = ld<f32x4>(R0 + i), b = ld<f32x4>(R1 + i);
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (NUM == 3) c = ld<f32x4>(R2 + i);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = te_sd(a[e], x[e]) + te_sd(b[e], x[e]);
+        if constexpr (NUM == 3) s = s + te_sd(c[e], x[e]);
+        o[e] = x[e] * s;
+      }
+      st<f32x4>(out + i, o);
+    } else {
+      const float x = X[i];
+      float s = te_sd(R0[i], x) + te_sd(R1[i], x);
+      if constexpr (NUM == 3) s = s + te_sd(R2[i], x);
+      out[i] = x * s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// IndexSelect.relprop (modules/layers_ours.py:129-147), dim = 1, single index.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void index_select_kernel(
+    const float* __restrict__ R, const float* __restrict__ X, float* __restrict__ out,
+    int64_t B, int64_t N, int64_t C, int64_t index) {
+  const int64_t total = B * N * C;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
+    const int64_t c = i % C;
+    const int64_t nrow = (i / C) % N;
+    const int64_t b = i / (C * N);
+    float v = 0.0f;
+    if (nrow == index) {
+      const float x = X[i];
+      v = x * te_sd(R[b * C + c], x);
+    }
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail a10: out[b,e] = (sum_h max(grad[b,h,e] * cam[b,h,e], 0)) / H over e in [0, N*N)
+// (ViT_LRP.py:359-366; ExplanationGenerator.py:49-56).  torch's mean sums heads in order then divides.
+// Per-(b,h) bases are (b*H+h)*N*N elements: only dword-aligned when N*N is odd, hence f32x4_u.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void headmean_kernel(
+    const float* __restrict__ grad, const float* __restrict__ cam, float* __restrict__ out,
+    int64_t H, int64_t NN) {
+  const int64_t b = blockIdx.y;
+  const float fH = (float)H;
+  const float* g = grad + b * H * NN;
+  const float* c = cam + b * H * NN;
+  float* o = out + b * NN;
+  const int64_t stride = (int64_t)gridDim.x * kThreads * VEC;
+  for (int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * VEC; e < NN; e += stride) {
+    if (VEC == 4 && e + 3 < NN) {
+      f32x4_u acc = {0.f, 0.f, 0.f, 0.f};
+      for (int64_t h = 0; h < H; ++h) {
+        const f32x4_u gv = ld<f32x4_u>(g + h * NN + e), cv = ld<f32x4_u>(c + h * NN + e);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k] + fmaxf(gv[k] * cv[k], 0.0f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = acc[k] / fH;
+      st<f32x4_u>(o + e, acc);
+    } else {
+      const int64_t lim = min(NN, e + VEC);
+      for (int64_t ee = e; ee < lim; ++ee) {
+        float acc = 0.0f;
+        for (int64_t h = 0; h < H; ++h) acc = acc + fmaxf(g[h * NN + ee] * c[h * NN + ee], 0.0f);
+        o[ee] = acc / fH;
+      }
+    }
+  }
+}
+
+inline int pick_blocks_per_sample(int64_t B, int64_t n) {
+  // >= ~2048 blocks in flight for the chip (256 CUs x 8), each block >= 4096 elements, <= 64 chunks.
+  int64_t bps = te_ceil_div(2048, B);
+  const int64_t max_by_size = te_ceil_div(n, 4096);
+  if (bps > max_by_size) bps = max_by_size;
+  if (bps > 64) bps = 64;
+  if (bps < 1) bps = 1;
+  return (int)bps;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" size_t te_add_relprop_workspace_bytes(int64_t B, int64_t n) {
+  if (B <= 0 || n <= 0) return 0;
+  return te_align_up((size_t)B * 64 * 3 * sizeof(double), 256);
+}
+
+extern "C" int te_add_relprop_f32(const float* R, const float* X0, const float* X1, float* out0,
+                                  float* out1, int64_t B, int64_t n, int64_t x1_batch_stride,
+                                  int variant, void* ws, size_t ws_bytes, te_stream_t stream_) {
+  if (!R || !X0 || !X1 || !out0 || !out1 || B <= 0 || n <= 0) return TE_ERR_INVALID_ARG;
+  if (x1_batch_stride != 0 && x1_batch_stride != n) return TE_ERR_INVALID_ARG;
+  const int var = variant & 0xff;
+  if (var != TE_VARIANT_OURS && var != TE_VARIANT_LRP) return TE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool vec = (n % 4 == 0) && te_aligned16(R) && te_aligned16(X0) && te_aligned16(X1) &&
+                   te_aligned16(out0) && te_aligned16(out1);
+  const int bps = pick_blocks_per_sample(B, n);
+  int64_t chunk = te_ceil_div(n, bps);
+  chunk = te_ceil_div(chunk, 4) * 4;
+  dim3 grid(bps, (unsigned)B), block(kThreads);
+  double* partial = (double*)ws;
+  if (var == TE_VARIANT_OURS) {
+    if (!ws || ws_bytes < te_add_relprop_workspace_bytes(B, n)) return TE_ERR_WORKSPACE;
+    if (vec) {
+      add_sums_kernel<4><<<grid, block, 0, stream>>>(R, X0, X1, partial, n, x1_batch_stride, chunk);
+      add_apply_kernel<4, true><<<grid, block, 0, stream>>>(R, X0, X1, out0, out1, partial, n,
+                                                            x1_batch_stride, chunk);
+    } else {
+      add_sums_kernel<1><<<grid, block, 0, stream>>>(R, X0, X1, partial, n, x1_batch_stride, chunk);
+      add_apply_kernel<1, true><<<grid, block, 0, stream>>>(R, X0, X1, out0, out1, partial, n,
+                                                            x1_batch_stride, chunk);
+    }
+  } else {
+    if (vec)
+      add_apply_kernel<4, false><<<grid, block, 0, stream>>>(R, X0, X1, out0, out1, nullptr, n,
+                                                             x1_batch_stride, chunk);
+    else
+      add_apply_kernel<1, false><<<grid, block, 0, stream>>>(R, X0, X1, out0, out1, nullptr, n,
+                                                             x1_batch_stride, chunk);
+  }
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// ---- broadcast-mask Add ---------------------------------------------------------------------------
+namespace {
+inline int addb_blocks(int64_t B, int64_t rows) {
+  int64_t nb = te_ceil_div(1024, B);
+  if (nb > rows) nb = rows;
+  if (nb > 64) nb = 64;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+}  // namespace
+
+extern "C" size_t te_add_bcast_relprop_workspace_bytes(int64_t B, int64_t H, int64_t N) {
+  if (B <= 0 || H <= 0 || N <= 0) return 0;
+  const size_t part = te_align_up((size_t)B * 64 * (N + 2) * sizeof(double), 256);
+  const size_t fac = te_align_up((size_t)B * 2 * sizeof(float), 256);
+  const size_t bvec = te_align_up((size_t)B * N * sizeof(float), 256);
+  return part + fac + bvec;
+}
+
+extern "C" int te_add_bcast_relprop_f32(const float* R, const float* X0, const float* mask,
+                                        float* out0, float* out1, int64_t B, int64_t H, int64_t N,
+                                        int variant, void* ws, size_t ws_bytes, te_stream_t stream_) {
+  if (!R || !X0 || !mask || !out0 || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
+  const int var = variant & 0xff;
+  if (var != TE_VARIANT_OURS && var != TE_VARIANT_LRP) return TE_ERR_INVALID_ARG;
+  if (N > (int64_t)kMaxColsPerThread * kThreads) return TE_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < te_add_bcast_relprop_workspace_bytes(B, H, N)) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t rows = H * N;
+  const int nblk = addb_blocks(B, rows);
+  const int64_t rpb = te_ceil_div(rows, nblk);
+  char* p = (char*)ws;
+  double* partial = (double*)p;
+  p += te_align_up((size_t)B * 64 * (N + 2) * sizeof(double), 256);
+  float* fac = (float*)p;
+  p += te_align_up((size_t)B * 2 * sizeof(float), 256);
+  float* bvec = (float*)p;
+  dim3 grid(nblk, (unsigned)B), block(kThreads);
+  addb_sums_kernel<<<grid, block, 0, stream>>>(R, X0, mask, partial, rows, N, rpb);
+  addb_finalize_kernel<<<dim3((unsigned)B), block, 0, stream>>>(partial, mask, fac, bvec, N, nblk,
+                                                               var == TE_VARIANT_OURS ? 1 : 0);
+  addb_apply_kernel<<<grid, block, 0, stream>>>(R, X0, mask, fac, bvec, out0, out1, rows, N, rpb);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// ---- Clone ------------------------------------------------------------------------------------------
+extern "C" int te_clone_relprop_f32(const float* R0, const float* R1, const float* R2, const float* X,
+                                    float* out, int64_t n, te_stream_t stream_) {
+  if (!R0 || !R1 || !X || !out || n <= 0) return TE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool vec = (n % 4 == 0) && te_aligned16(R0) && te_aligned16(R1) && te_aligned16(X) &&
+                   te_aligned16(out) && (!R2 || te_aligned16(R2));
+  const int vecw = vec ? 4 : 1;
+  int64_t blocks = te_ceil_div(n, (int64_t)kThreads * vecw * 2);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  dim3 grid((unsigned)blocks), block(kThreads);
+  if (R2) {
+    if (vec) clone_kernel<4, 3><<<grid, block, 0, stream>>>(R0, R1, R2, X, out, n);
+    else clone_kernel<1, 3><<<grid, block, 0, stream>>>(R0, R1, R2, X, out, n);
+  } else {
+    if (vec) clone_kernel<4, 2><<<grid, block, 0, stream>>>(R0, R1, nullptr, X, out, n);
+    else clone_kernel<1, 2><<<grid, block, 0, stream>>>(R0, R1, nullptr, X, out, n);
+  }
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// ---- IndexSelect ------------------------------------------------------------------------------------
+extern "C" int te_index_select_relprop_f32(const float* R, const float* X, float* out, int64_t B,
+                                           int64_t N, int64_t C, int64_t index, te_stream_t stream_) {
+  if (!R || !X || !out || B <= 0 || N <= 0 || C <= 0 || index < 0 || index >= N)
+    return TE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int64_t blocks = te_ceil_div(B * N * C, (int64_t)kThreads * 4);
+  if (blocks > 4096) blocks = 4096;
+  index_select_kernel<<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(R, X, out, B, N, C, index);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// ---- gradient x relevance head mean ----------------------------------------------------------------
+extern "C" int te_gradcam_headmean_f32(const float* grad, const float* cam, float* out, int64_t B,
+                                       int64_t H, int64_t N, te_stream_t stream_) {
+  if (!grad || !cam || !out || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t NN = N * N;
+  int64_t bx = te_ceil_div(NN, (int64_t)kThreads * 4);
+  const int64_t want = te_ceil_div(2048, B);
+  if (bx > want) bx = want;
+  if (bx < 1) bx = 1;
+  headmean_kernel<4><<<dim3((unsigned)bx, (unsigned)B), dim3(kThreads), 0, stream>>>(grad, cam, out, H, NN);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}

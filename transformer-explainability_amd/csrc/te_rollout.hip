@@ -1,0 +1,155 @@
+// te_rollout.hip -- compute_rollout_attention (ViT_LRP.py:38-49 un-normalised; ExplanationGenerator.py:7-18
+// row-normalised) and the BERT CLS fix-up (ExplanationGenerator.py:58) for gfx950.
+//
+//   M_l = cams_l + I  [/ rowsum(M_l)] ;  J = M_start ;  J = M_i J  (i = start+1 .. L-1)
+//
+// prep kernel: one wave per row builds M_l in the workspace (adds the identity, optional row
+// normalisation with the row sum taken in index order like torch.sum over the last dim).
+// chain kernel: batched (N x N)(N x N) fp32 product, 64 x 64 output tile per 256-thread block staged
+// through LDS in 16-deep K slices, 4 x 4 register micro-tile per thread, k-ordered fmaf chains.
+#include "te_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int TS = 64, KS = 16;
+
+__global__ __launch_bounds__(kThreads) void rollout_prep_kernel(const float* __restrict__ cams,
+                                                                float* __restrict__ M, int64_t rows, int64_t N,
+                                                                int normalise) {
+  // rows = L*B*N matrix rows; one wave per row
+  const int64_t row = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = row % N;
+  const float* src = cams + row * N;
+  float* dst = M + row * N;
+  float inv_den = 1.0f;
+  float den = 0.0f;
+  if (normalise) {
+    double s = 0.0;
+    for (int64_t j = lane; j < N; j += 64) s += (double)(src[j] + (j == i ? 1.0f : 0.0f));
+    s = te_wave_sum(s);
+    s = __shfl(s, 0, 64);
+    den = (float)s;
+  }
+  (void)inv_den;
+  for (int64_t j = lane; j < N; j += 64) {
+    float v = src[j] + (j == i ? 1.0f : 0.0f);
+    if (normalise) v = v / den;
+    dst[j] = v;
+  }
+}
+
+// C[b] = A[b] * Bm[b], all N x N row-major
+__global__ __launch_bounds__(kThreads) void rollout_bmm_kernel(const float* __restrict__ A,
+                                                               const float* __restrict__ Bm, float* __restrict__ C,
+                                                               int64_t N) {
+  __shared__ float As[KS][TS + 1];
+  __shared__ float Bs[KS][TS + 1];
+  const int64_t b = blockIdx.z;
+  const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+  const float* a = A + b * N * N;
+  const float* bm = Bm + b * N * N;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+  for (int64_t k0 = 0; k0 < N; k0 += KS) {
+    // A tile [64 rows][16 k] -> As[k][row];  B tile [16 k][64 cols] -> Bs[k][col]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int idx = threadIdx.x + t * kThreads;  // 0..1023
+      const int ar = idx >> 4, ak = idx & 15;
+      const int64_t gr = r0 + ar, gk = k0 + ak;
+      As[ak][ar] = (gr < N && gk < N) ? a[gr * N + gk] : 0.0f;
+      const int bk = idx >> 6, bc = idx & 63;
+      const int64_t gk2 = k0 + bk, gc = c0 + bc;
+      Bs[bk][bc] = (gk2 < N && gc < N) ? bm[gk2 * N + gc] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t gr = r0 + ty * 4 + i, gc = c0 + tx * 4 + j;
+      if (gr < N && gc < N) C[b * N * N + gr * N + gc] = acc[i][j];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void rollout_copy_kernel(const float* __restrict__ src,
+                                                                float* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+// joint[b,0,0] = min_j joint[b,0,j]     (ExplanationGenerator.py:58)
+__global__ __launch_bounds__(64) void rollout_cls_fixup_kernel(float* __restrict__ joint, int64_t N) {
+  float* row = joint + (int64_t)blockIdx.x * N * N;
+  float m = INFINITY;
+  for (int64_t j = threadIdx.x; j < N; j += 64) m = fminf(m, row[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_down(m, off, 64));
+  if (threadIdx.x == 0) row[0] = m;
+}
+
+}  // namespace
+
+// workspace: M [L,B,N,N] (identity added / normalised copies) + one ping-pong joint [B,N,N]
+extern "C" size_t te_rollout_workspace_bytes(int64_t L, int64_t B, int64_t N) {
+  if (L <= 0 || B <= 0 || N <= 0) return 0;
+  const size_t m = te_align_up((size_t)L * B * N * N * sizeof(float), 256);
+  const size_t j = te_align_up((size_t)B * N * N * sizeof(float), 256);
+  return m + j;
+}
+
+extern "C" int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
+                              int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream_) {
+  if (!cams || !joint || L <= 0 || B <= 0 || N <= 0 || start_layer < 0 || start_layer >= L)
+    return TE_ERR_INVALID_ARG;
+  if (!ws || ws_bytes < te_rollout_workspace_bytes(L, B, N)) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t mat = B * N * N;
+  float* M = (float*)ws;
+  float* tmp = (float*)((char*)ws + te_align_up((size_t)L * mat * sizeof(float), 256));
+  // only layers start..L-1 are consumed
+  const int64_t rows = (L - start_layer) * B * N;
+  rollout_prep_kernel<<<dim3((unsigned)te_ceil_div(rows, kThreads / 64)), dim3(kThreads), 0, stream>>>(
+      cams + start_layer * mat, M + start_layer * mat, rows, N, (flags & TE_ROLLOUT_NORMALISE) ? 1 : 0);
+  const int64_t steps = L - 1 - start_layer;
+  // ping-pong so that the last product lands in `joint`
+  const float* cur = M + start_layer * mat;
+  dim3 grid((unsigned)te_ceil_div(N, TS), (unsigned)te_ceil_div(N, TS), (unsigned)B), blk(kThreads);
+  if (steps == 0) {
+    int64_t blocks = te_ceil_div(mat, (int64_t)kThreads * 4);
+    if (blocks > 4096) blocks = 4096;
+    rollout_copy_kernel<<<dim3((unsigned)blocks), blk, 0, stream>>>(cur, joint, mat);
+  } else {
+    for (int64_t s = 0; s < steps; ++s) {
+      const int64_t i = start_layer + 1 + s;
+      float* dst = ((steps - 1 - s) % 2 == 0) ? joint : tmp;
+      rollout_bmm_kernel<<<grid, blk, 0, stream>>>(M + i * mat, cur, dst, N);
+      cur = dst;
+    }
+  }
+  if (flags & TE_ROLLOUT_CLS_FIXUP)
+    rollout_cls_fixup_kernel<<<dim3((unsigned)B), dim3(64), 0, stream>>>(joint, N);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}

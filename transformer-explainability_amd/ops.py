@@ -1,0 +1,251 @@
+"""Tensor-level wrappers over the C ABI: shape/stride plumbing, output + workspace allocation.
+
+Every function takes fp32 tensors that live on one MI355X, enqueues HIP kernels on torch's current
+stream for that device and returns torch tensors (no synchronisation).  Shapes follow the reference's
+relprop rules; see include/te_relprop.h for the exact semantics and reference citations.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TE_IMPL_SIMPLE, TE_ROLLOUT_CLS_FIXUP, TE_ROLLOUT_NORMALISE, TE_VARIANT_LRP, TE_VARIANT_OURS
+
+Tensor = torch.Tensor
+_VARIANTS = {"ours": TE_VARIANT_OURS, "lrp": TE_VARIANT_LRP}
+
+# Tests flip this to run the simple (non-MFMA) device kernels as an on-device cross-check.
+FORCE_SIMPLE = False
+# bench.py installs a callable (name, flops) -> context manager here to time single kernel launches.
+KERNEL_TIMER = None
+_checked_device = False
+
+
+def _variant(v) -> int:
+    code = _VARIANTS[v] if isinstance(v, str) else int(v)
+    return code | (TE_IMPL_SIMPLE if FORCE_SIMPLE else 0)
+
+
+def _prep(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.TeError(f"relprop kernels are fp32-only, got {t.dtype}")
+    if not t.is_cuda:
+        raise _lib.TeError("relprop kernels need tensors on the MI355X (got a CPU tensor); there is no CPU fallback")
+    return t
+
+
+def _c(t: Tensor) -> Tensor:
+    t = _prep(t)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ws(nbytes: int, like: Tensor) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+
+
+class _on_device:
+    """Make the tensor's device current for the duration of the call (multi-GPU processes)."""
+
+    def __init__(self, t: Tensor):
+        global _checked_device
+        _prep(t)
+        if not _checked_device:
+            _lib.require_device()
+            _checked_device = True
+        self.ctx = torch.cuda.device(t.device)
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        return _lib.load()
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+
+# ---------------------------------------------------------------------------------------- a3
+def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant="ours") -> Tensor:
+    """Linear.relprop: R [..., out], X [..., in], W [out, in] -> [..., in]."""
+    out_f, in_f = W.shape
+    lead = X.shape[:-1]
+    Rc, Xc, Wc = _c(R).reshape(-1, out_f), _c(X).reshape(-1, in_f), _c(W)
+    T = Xc.shape[0]
+    if Rc.shape[0] != T:
+        raise _lib.TeError(f"Linear.relprop: R has {Rc.shape[0]} rows, X has {T}")
+    out = torch.empty((T, in_f), dtype=torch.float32, device=X.device)
+    var = _variant(variant)
+    if KERNEL_TIMER is not None and var == TE_VARIANT_OURS and alpha == 1 and in_f % 4 == 0 and out_f % 4 == 0:
+        # bench.py roofline probe: same two kernels, launched one by one so that each launch can be
+        # bracketed by HIP events on the stream it runs on
+        with _on_device(Xc) as lib:
+            S = torch.empty((T, out_f), dtype=torch.float32, device=X.device)
+            st = _stream(Xc)
+            with KERNEL_TIMER("linear_zpass", 2.0 * T * (2 * in_f) * out_f):
+                _lib.check(lib.te_linear_zpass_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(S), T, in_f, out_f, st),
+                           "te_linear_zpass_f32")
+            with KERNEL_TIMER("linear_cpass", 2.0 * T * (2 * in_f) * out_f):
+                _lib.check(lib.te_linear_cpass_f32(_ptr(S), _ptr(Xc), _ptr(Wc), _ptr(out), T, in_f, out_f, st),
+                           "te_linear_cpass_f32")
+        return out.reshape(*lead, in_f)
+    with _on_device(Xc) as lib:
+        ws = _ws(lib.te_linear_relprop_workspace_bytes(T, in_f, out_f, var), Xc)
+        _lib.check(lib.te_linear_relprop_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(out), T, in_f, out_f, float(alpha),
+                                             var, _ptr(ws), ws.numel(), _stream(Xc)), "te_linear_relprop_f32")
+    return out.reshape(*lead, in_f)
+
+
+# ---------------------------------------------------------------------------------------- a4
+def _bhnd(t: Tensor) -> Tuple[Tensor, int, int, int]:
+    """[B,H,N,D] view with contiguous D -> (tensor, sb, sh, sn) in elements (copy only if needed)."""
+    t = _prep(t)
+    if t.stride(-1) != 1 or min(t.stride()[:3]) < 0:
+        t = t.contiguous()
+    sb, sh, sn, _ = t.stride()
+    return t, sb, sh, sn
+
+
+def matmul_relprop_av(R: Tensor, attn: Tensor, v: Tensor, out_scale: float = 1.0,
+                      cam_v_out: Optional[Tensor] = None, variant="ours") -> Tuple[Tensor, Tensor]:
+    """AV rule.  R, v: [B,H,N,D] (any strides with contiguous D); attn [B,H,N,N].
+    Returns (cam_attn [B,H,N,N], cam_v [B,H,N,D]); cam_v is written into `cam_v_out` if given (a
+    [B,H,N,D] view, e.g. a slice of the 'b n (qkv h d)' relevance buffer)."""
+    B, H, N, D = v.shape
+    R, r_sb, r_sh, r_sn = _bhnd(R)
+    v, v_sb, v_sh, v_sn = _bhnd(v)
+    attn = _c(attn)
+    cam_attn = torch.empty((B, H, N, N), dtype=torch.float32, device=attn.device)
+    cam_v = cam_v_out if cam_v_out is not None else torch.empty((B, H, N, D), dtype=torch.float32, device=attn.device)
+    if cam_v.stride(-1) != 1:
+        raise _lib.TeError("cam_v_out must have a contiguous last dim")
+    cv_sb, cv_sh, cv_sn, _ = cam_v.stride()
+    with _on_device(attn) as lib:
+        ws = _ws(lib.te_matmul_relprop_av_workspace_bytes(B, H, N, D), attn)
+        _lib.check(lib.te_matmul_relprop_av_f32(
+            _ptr(R), r_sb, r_sh, r_sn, _ptr(attn), _ptr(v), v_sb, v_sh, v_sn, _ptr(cam_attn),
+            _ptr(cam_v), cv_sb, cv_sh, cv_sn, B, H, N, D, float(out_scale), _variant(variant),
+            _ptr(ws), ws.numel(), _stream(attn)), "te_matmul_relprop_av_f32")
+    return cam_attn, cam_v
+
+
+def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
+                      cam_q_out: Optional[Tensor] = None, cam_k_out: Optional[Tensor] = None,
+                      variant="ours") -> Tuple[Tensor, Tensor]:
+    """QK rule.  R [B,H,N,N]; q, k [B,H,N,D] -> (cam_q, cam_k) [B,H,N,D]."""
+    B, H, N, D = q.shape
+    q, q_sb, q_sh, q_sn = _bhnd(q)
+    k, k_sb, k_sh, k_sn = _bhnd(k)
+    R = _c(R)
+    dev = R.device
+    cam_q = cam_q_out if cam_q_out is not None else torch.empty((B, H, N, D), dtype=torch.float32, device=dev)
+    cam_k = cam_k_out if cam_k_out is not None else torch.empty((B, H, N, D), dtype=torch.float32, device=dev)
+    if cam_q.stride(-1) != 1 or cam_k.stride(-1) != 1:
+        raise _lib.TeError("cam_q_out / cam_k_out must have a contiguous last dim")
+    cq, ck = cam_q.stride(), cam_k.stride()
+    with _on_device(R) as lib:
+        ws = _ws(lib.te_matmul_relprop_qk_workspace_bytes(B, H, N, D), R)
+        _lib.check(lib.te_matmul_relprop_qk_f32(
+            _ptr(R), _ptr(q), q_sb, q_sh, q_sn, _ptr(k), k_sb, k_sh, k_sn,
+            _ptr(cam_q), cq[0], cq[1], cq[2], _ptr(cam_k), ck[0], ck[1], ck[2],
+            B, H, N, D, float(out_scale), _variant(variant), _ptr(ws), ws.numel(), _stream(R)),
+            "te_matmul_relprop_qk_f32")
+    return cam_q, cam_k
+
+
+# ---------------------------------------------------------------------------------------- a5
+def add_relprop(R: Tensor, X0: Tensor, X1: Tensor, variant="ours") -> Tuple[Tensor, Tensor]:
+    """Add.relprop with per-sample sums.  dim 0 is the batch.  X1 has X0's shape, or batch 1 (shared by
+    all samples), or is the BERT broadcast mask [B,1,1,N] against X0 [B,H,N,N]."""
+    B = X0.shape[0]
+    R, X0 = _c(R), _c(X0)
+    n = X0[0].numel()
+    if X1.dim() == 4 and X0.dim() == 4 and X1.shape[1] == 1 and X1.shape[2] == 1 and X0.shape[1] * X0.shape[2] != 1:
+        H, N = X0.shape[1], X0.shape[3]
+        mask = _c(X1).reshape(X1.shape[0], N)
+        if mask.shape[0] == 1 and B > 1:
+            mask = mask.expand(B, N).contiguous()
+        out0 = torch.empty_like(X0)
+        out1 = torch.empty((B, 1, 1, N), dtype=torch.float32, device=X0.device)
+        with _on_device(X0) as lib:
+            ws = _ws(lib.te_add_bcast_relprop_workspace_bytes(B, H, N), X0)
+            _lib.check(lib.te_add_bcast_relprop_f32(_ptr(R), _ptr(X0), _ptr(mask), _ptr(out0), _ptr(out1), B, H, N,
+                                                    _variant(variant), _ptr(ws), ws.numel(), _stream(X0)),
+                       "te_add_bcast_relprop_f32")
+        return out0, out1
+    X1 = _c(X1)
+    if X1.shape == X0.shape:
+        x1_bs = n
+    elif X1.shape[0] == 1 and X1.shape[1:] == X0.shape[1:]:
+        x1_bs = 0
+    else:
+        raise _lib.TeError(f"Add.relprop: unsupported operand shapes {tuple(X0.shape)} + {tuple(X1.shape)}")
+    out0, out1 = torch.empty_like(X0), torch.empty_like(X0)
+    with _on_device(X0) as lib:
+        ws = _ws(lib.te_add_relprop_workspace_bytes(B, n), X0)
+        _lib.check(lib.te_add_relprop_f32(_ptr(R), _ptr(X0), _ptr(X1), _ptr(out0), _ptr(out1), B, n, x1_bs,
+                                          _variant(variant), _ptr(ws), ws.numel(), _stream(X0)), "te_add_relprop_f32")
+    return out0, out1
+
+
+# ---------------------------------------------------------------------------------------- a6
+def clone_relprop(Rs: Sequence[Tensor], X: Tensor) -> Tensor:
+    if len(Rs) not in (2, 3):
+        raise _lib.TeError(f"Clone.relprop supports 2 or 3 aliases, got {len(Rs)}")
+    X = _c(X)
+    Rs = [_c(r) for r in Rs]
+    for r in Rs:
+        if r.numel() != X.numel():
+            raise _lib.TeError("Clone.relprop: relevance / input size mismatch")
+    out = torch.empty_like(X)
+    with _on_device(X) as lib:
+        _lib.check(lib.te_clone_relprop_f32(_ptr(Rs[0]), _ptr(Rs[1]), _ptr(Rs[2]) if len(Rs) == 3 else None, _ptr(X),
+                                            _ptr(out), X.numel(), _stream(X)), "te_clone_relprop_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- a7
+def index_select_relprop(R: Tensor, X: Tensor, index: int) -> Tensor:
+    """IndexSelect.relprop for dim=1: R [B,1,C] or [B,C], X [B,N,C] -> [B,N,C]."""
+    X = _c(X)
+    B, N, C = X.shape
+    R = _c(R).reshape(B, C)
+    out = torch.empty_like(X)
+    with _on_device(X) as lib:
+        _lib.check(lib.te_index_select_relprop_f32(_ptr(R), _ptr(X), _ptr(out), B, N, C, int(index), _stream(X)),
+                   "te_index_select_relprop_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- a10
+def gradcam_headmean(grad: Tensor, cam: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """grad, cam [B,H,N,N] -> [B,N,N] = mean_h max(grad*cam, 0), per sample."""
+    grad, cam = _c(grad), _c(cam)
+    B, H, N, _ = cam.shape
+    if out is None:
+        out = torch.empty((B, N, N), dtype=torch.float32, device=cam.device)
+    with _on_device(cam) as lib:
+        _lib.check(lib.te_gradcam_headmean_f32(_ptr(grad), _ptr(cam), _ptr(out), B, H, N, _stream(cam)),
+                   "te_gradcam_headmean_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- a11
+def rollout(cams: Tensor, start_layer: int = 0, normalise: bool = False, cls_fixup: bool = False) -> Tensor:
+    """cams [L,B,N,N] -> joint [B,N,N] (compute_rollout_attention)."""
+    cams = _c(cams)
+    L, B, N, _ = cams.shape
+    joint = torch.empty((B, N, N), dtype=torch.float32, device=cams.device)
+    flags = (TE_ROLLOUT_NORMALISE if normalise else 0) | (TE_ROLLOUT_CLS_FIXUP if cls_fixup else 0)
+    with _on_device(cams) as lib:
+        ws = _ws(lib.te_rollout_workspace_bytes(L, B, N), cams)
+        _lib.check(lib.te_rollout_f32(_ptr(cams), L, int(start_layer), B, N, flags, _ptr(joint), _ptr(ws), ws.numel(),
+                                      _stream(cams)), "te_rollout_f32")
+    return joint

@@ -1,0 +1,69 @@
+"""Multi-GPU: one process per GPU, samples sharded with no data-path communication, one gather of the
+finished maps (RCCL over xGMI on MI355X; gloo in the CPU tests).
+
+Every image / sequence is an independent problem (per-sample semantics), so fwd, bwd and relprop never
+communicate; weights are read-only replicas.  The only collective is the final all_gather of the
+[n_local, N-1] fp32 maps (25 KB per rank per step at B = 256 over 8 GPUs -- latency-bound, so it is
+issued once per sweep, not per step).  The reference has no equivalent (its utils/parallel.py is dead
+code).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
+    Single-process runs (no RANK in the environment) are a no-op returning (0, 1, 0)."""
+    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return 0, 1, 0
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition [lo, hi) of n_items over `world` ranks (first ranks get the remainder)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> range:
+    lo, hi = shard_range(n_items, rank, world)
+    return range(lo, hi)
+
+
+def gather_maps(local_maps: torch.Tensor, n_items: int) -> torch.Tensor:
+    """All-gather the per-rank [n_local, M] maps into the full [n_items, M] tensor in global order.
+    Ranks may own different counts (block partition); shards are padded to the largest for the
+    collective and trimmed afterwards."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_maps
+    world = dist.get_world_size()
+    counts = [shard_range(n_items, r, world) for r in range(world)]
+    max_n = max(hi - lo for lo, hi in counts)
+    M = local_maps.shape[1:]
+    pad = torch.zeros((max_n, *M), dtype=local_maps.dtype, device=local_maps.device)
+    pad[: local_maps.shape[0]] = local_maps
+    out = torch.empty((world, max_n, *M), dtype=local_maps.dtype, device=local_maps.device)
+    dist.all_gather_into_tensor(out, pad.contiguous()) if hasattr(dist, "all_gather_into_tensor") and \
+        local_maps.is_cuda else dist.all_gather(list(out.unbind(0)), pad.contiguous())
+    return torch.cat([out[r, : hi - lo] for r, (lo, hi) in enumerate(counts)], 0)
+
+
+def synthetic_image(global_index: int, shape=(3, 224, 224), seed: int = 1) -> torch.Tensor:
+    """Deterministic synthetic sample keyed by its GLOBAL index, so any shard layout sees the same data."""
+    g = torch.Generator().manual_seed(seed * 1_000_003 + global_index)
+    return torch.randn(shape, generator=g, dtype=torch.float32)

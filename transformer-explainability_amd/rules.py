@@ -1,0 +1,226 @@
+"""Relprop rule classes -- host-side mirror of the reference's rule library, backed by HIP kernels.
+
+Same class names, constructor signatures, ``forward`` behaviour, ``self.X`` / ``self.Y`` state
+convention and ``relprop(R, alpha)`` signature as modules/layers_ours.py (variant "ours") and
+modules/layers_lrp.py (variant "lrp") of the reference, and their BERT copies
+(BERT_explainability/modules/layers_ours.py, layers_lrp.py: + MatMul, Mul, Tanh).  The reference
+evaluates each rule with ``torch.autograd.grad`` on a re-built micro-graph (layers_ours.py:41-43);
+here ``relprop`` calls one fused closed-form kernel through the C ABI (include/te_relprop.h).
+
+Batch semantics: the reference is batch-1 only; a batch of B samples is B independent batch-1
+problems (Add's "whole tensor" sums are per sample).  With B = 1 the results match the reference.
+
+Off the accelerated hot path ("API surface"): Conv2d / BatchNorm2d / pools /
+Cat / AddEye / Mul keep their forward so models build and run, but their relprop (used only by
+method="full") raises NotImplementedError here.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+__all__ = ['forward_hook', 'Clone', 'Add', 'Cat', 'ReLU', 'GELU', 'Dropout', 'BatchNorm2d', 'Linear', 'MaxPool2d',
+           'AdaptiveAvgPool2d', 'AvgPool2d', 'Conv2d', 'Sequential', 'safe_divide', 'einsum', 'Softmax',
+           'IndexSelect', 'LayerNorm', 'AddEye', 'Tanh', 'MatMul', 'Mul']
+
+
+def safe_divide(a, b):
+    """modules/layers_ours.py:10-13 (plain torch; host-side helper, not used by the kernels)."""
+    den = b.clamp(min=1e-9) + b.clamp(max=1e-9)
+    den = den + den.eq(0).type(den.type()) * 1e-9
+    return a / den * b.ne(0).type(b.type())
+
+
+def forward_hook(self, input, output):
+    """Capture the detached input(s) as self.X and the output as self.Y (layers_ours.py:16-27).
+    No copy is made: detach() aliases the activation the forward pass produced."""
+    if type(input[0]) in (list, tuple):
+        self.X = [i.detach() for i in input[0]]
+    else:
+        self.X = input[0].detach()
+    self.Y = output
+
+
+class RelProp(nn.Module):
+    variant = "ours"
+
+    def __init__(self):
+        super(RelProp, self).__init__()
+        self.register_forward_hook(forward_hook)
+
+    def relprop(self, R, alpha):
+        return R
+
+
+class _Identity(RelProp):
+    """Rules that pass relevance through unchanged (layers_ours.py:67-80,86-87) need no cached input."""
+
+
+def _no_cache_hook(self, input, output):
+    self.Y = output
+
+
+class ReLU(nn.ReLU, RelProp):
+    pass
+
+
+class GELU(nn.GELU, RelProp):
+    pass
+
+
+class Softmax(nn.Softmax, RelProp):
+    pass
+
+
+class LayerNorm(nn.LayerNorm, RelProp):
+    pass
+
+
+class Dropout(nn.Dropout, RelProp):
+    pass
+
+
+class Tanh(nn.Tanh, RelProp):
+    pass
+
+
+# ------------------------------------------------------------------------------------------ hot path
+class Linear(nn.Linear, RelProp):
+    """layers_ours.py:207-230 / layers_lrp.py:188-211 -> te_linear_relprop_f32."""
+
+    def relprop(self, R, alpha):
+        return ops.linear_relprop(R, self.X, self.weight.detach(), alpha=alpha, variant=self.variant)
+
+
+class Add(RelProp):
+    """layers_ours.py:97-120 (ours) / layers_lrp.py:98-100 (lrp) -> te_add_relprop_f32 /
+    te_add_bcast_relprop_f32 (broadcast mask operand of BERT self-attention)."""
+
+    def forward(self, inputs):
+        return torch.add(*inputs)
+
+    def relprop(self, R, alpha):
+        a, b = ops.add_relprop(R, self.X[0], self.X[1], variant=self.variant)
+        return [a, b]
+
+
+class einsum(RelProp):
+    """layers_ours.py:122-127 (RelPropSimple) for the two attention products."""
+
+    def __init__(self, equation):
+        super().__init__()
+        self.equation = equation
+
+    def forward(self, *operands):
+        return torch.einsum(self.equation, *operands)
+
+    def relprop(self, R, alpha):
+        eq = self.equation.replace(" ", "")
+        if eq == 'bhij,bhjd->bhid':
+            cam_attn, cam_v = ops.matmul_relprop_av(R, self.X[0], self.X[1], variant=self.variant)
+            return [cam_attn, cam_v]
+        if eq == 'bhid,bhjd->bhij':
+            cam_q, cam_k = ops.matmul_relprop_qk(R, self.X[0], self.X[1], variant=self.variant)
+            return [cam_q, cam_k]
+        raise NotImplementedError(f"einsum.relprop: equation {self.equation!r} is not on the accelerated path")
+
+
+class MatMul(RelProp):
+    """BERT_explainability/modules/layers_ours.py:89-91: [probs, V] and [Q, K^T] products."""
+
+    def forward(self, inputs):
+        return torch.matmul(*inputs)
+
+    def relprop(self, R, alpha):
+        x0, x1 = self.X
+        if x0.dim() != 4 or x1.dim() != 4:
+            raise NotImplementedError("MatMul.relprop: only [B,H,.,.] attention products are accelerated")
+        if x1.stride(-1) != 1 and x1.stride(-2) == 1:          # [Q, K^T] with K^T a transposed view
+            k = x1.transpose(-1, -2)
+            cam_q, cam_k = ops.matmul_relprop_qk(R, x0, k, variant=self.variant)
+            return [cam_q, cam_k.transpose(-1, -2)]
+        if x0.shape[-1] == x0.shape[-2] == x1.shape[-2]:       # [probs, V]
+            cam_attn, cam_v = ops.matmul_relprop_av(R, x0, x1, variant=self.variant)
+            return [cam_attn, cam_v]
+        if x0.shape[-1] == x1.shape[-2]:                        # [Q, K^T] materialised contiguously
+            k = x1.transpose(-1, -2).contiguous()
+            cam_q, cam_k = ops.matmul_relprop_qk(R, x0, k, variant=self.variant)
+            return [cam_q, cam_k.transpose(-1, -2)]
+        raise NotImplementedError("MatMul.relprop: operand shapes are not an attention product")
+
+
+class Clone(RelProp):
+    """layers_ours.py:151-169 -> te_clone_relprop_f32."""
+
+    def forward(self, input, num):
+        self.__setattr__('num', num)
+        return [input for _ in range(num)]
+
+    def relprop(self, R, alpha):
+        return ops.clone_relprop(list(R), self.X)
+
+
+class IndexSelect(RelProp):
+    """layers_ours.py:129-147 -> te_index_select_relprop_f32 (dim 1, one index)."""
+
+    def forward(self, inputs, dim, indices):
+        self.__setattr__('dim', dim)
+        self.__setattr__('indices', indices)
+        return torch.index_select(inputs, dim, indices)
+
+    def relprop(self, R, alpha):
+        idx = self.indices
+        if self.dim != 1 or self.X.dim() != 3 or (torch.is_tensor(idx) and idx.numel() != 1):
+            raise NotImplementedError("IndexSelect.relprop: only dim=1 with a single index is accelerated")
+        return ops.index_select_relprop(R, self.X, int(idx))
+
+
+class Sequential(nn.Sequential):
+    def relprop(self, R, alpha):
+        for m in reversed(self._modules.values()):
+            R = m.relprop(R, alpha)
+        return R
+
+
+# ------------------------------------------------------------------------- API surface, off the hot path
+class _OffPath(RelProp):
+    def relprop(self, R, alpha):
+        raise NotImplementedError(f"{type(self).__name__}.relprop is off the accelerated transformer_attribution path")
+
+
+class Mul(_OffPath):
+    def forward(self, inputs):
+        return torch.mul(*inputs)
+
+
+class AddEye(_OffPath):
+    def forward(self, input):
+        return input + torch.eye(input.shape[2], device=input.device).expand_as(input)
+
+
+class Cat(_OffPath):
+    def forward(self, inputs, dim):
+        self.__setattr__('dim', dim)
+        return torch.cat(inputs, dim)
+
+
+class MaxPool2d(nn.MaxPool2d, _OffPath):
+    pass
+
+
+class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d, _OffPath):
+    pass
+
+
+class AvgPool2d(nn.AvgPool2d, _OffPath):
+    pass
+
+
+class BatchNorm2d(nn.BatchNorm2d, _OffPath):
+    pass
+
+
+class Conv2d(nn.Conv2d, _OffPath):
+    pass

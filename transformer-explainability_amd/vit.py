@@ -1,0 +1,285 @@
+"""ViT / DeiT with relevance propagation on MI355X kernels.
+
+Host-side mirror of baselines/ViT/ViT_LRP.py (rule variant "ours", default method
+"transformer_attribution") and baselines/ViT/ViT_orig_LRP.py (variant "lrp", method "grad") of the
+reference: same constructor arguments, parameter names (timm / reference checkpoints load
+unchanged), accessors (``blk.attn.get_attn()/get_attn_cam()/get_attn_gradients()/get_v()/
+get_v_cam()``) and ``model.relprop(cam, method=..., is_ablation=..., start_layer=..., alpha=1)``.
+
+What differs from the reference (by design, results identical at batch 1):
+  * forward + backward stay on stock PyTorch-ROCm; every ``relprop`` below is HIP kernels via the C ABI
+  * batch B >= 1 = B independent samples: relprop(one_hot[B,K]) returns [B, N-1]
+  * q/k/v are consumed in place from the fused qkv activation and cam_q/cam_k/cam_v are written in
+    place into the 'b n (qkv h d)' relevance buffer -- no rearrange copies (ViT_LRP.py:135,157,175)
+  * the /2 of ViT_LRP.py:161-162,172-173 is folded into the kernels' store (exact: power of two)
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import rules as R_ours
+
+__all__ = ["VisionTransformer", "vit_base_patch16_224", "vit_large_patch16_224", "deit_base_patch16_224",
+           "compute_rollout_attention", "make_vit_module"]
+
+
+def compute_rollout_attention(all_layer_matrices, start_layer=0):
+    """ViT_LRP.py:38-49 (identity added, NO row normalisation).  list of L [B,N,N] -> [B,N,N]."""
+    return ops.rollout(torch.stack(list(all_layer_matrices), 0), start_layer=start_layer, normalise=False)
+
+
+def _trunc_normal_(t, std=.02):
+    with torch.no_grad():
+        return nn.init.trunc_normal_(t, mean=0., std=std, a=-2., b=2.)
+
+
+def make_vit_module(L):
+    """Build the model classes over a rule namespace ``L`` (rules for 'ours', rules_lrp for 'lrp')."""
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.):
+            super().__init__()
+            out_features = out_features or in_features
+            hidden_features = hidden_features or in_features
+            self.fc1 = L.Linear(in_features, hidden_features)
+            self.act = L.GELU()
+            self.fc2 = L.Linear(hidden_features, out_features)
+            self.drop = L.Dropout(drop)
+
+        def forward(self, x):
+            return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+        def relprop(self, cam, **kwargs):
+            # ViT_LRP.py:69-74 -- dropout / GELU rules are the identity
+            cam = self.fc2.relprop(cam, **kwargs)
+            return self.fc1.relprop(cam, **kwargs)
+
+    class Attention(nn.Module):
+        def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+            super().__init__()
+            self.num_heads = num_heads
+            self.scale = (dim // num_heads) ** -0.5
+            self.matmul1 = L.einsum('bhid,bhjd->bhij')      # A = Q K^T
+            self.matmul2 = L.einsum('bhij,bhjd->bhid')      # out = A V
+            self.qkv = L.Linear(dim, dim * 3, bias=qkv_bias)
+            self.attn_drop = L.Dropout(attn_drop)
+            self.proj = L.Linear(dim, dim)
+            self.proj_drop = L.Dropout(proj_drop)
+            self.softmax = L.Softmax(dim=-1)
+            self.attn_cam = self.attn = self.v = self.v_cam = self.attn_gradients = None
+
+        # accessors of ViT_LRP.py:102-130
+        def get_attn(self): return self.attn
+        def save_attn(self, attn): self.attn = attn
+        def save_attn_cam(self, cam): self.attn_cam = cam
+        def get_attn_cam(self): return self.attn_cam
+        def get_v(self): return self.v
+        def save_v(self, v): self.v = v
+        def save_v_cam(self, cam): self.v_cam = cam
+        def get_v_cam(self): return self.v_cam
+        def save_attn_gradients(self, g): self.attn_gradients = g
+        def get_attn_gradients(self): return self.attn_gradients
+
+        def forward(self, x):
+            B, N, C = x.shape
+            H = self.num_heads
+            qkv = self.qkv(x).view(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)   # 'b n (qkv h d) -> qkv b h n d'
+            q, k, v = qkv[0], qkv[1], qkv[2]
+            self.save_v(v)
+            attn = self.attn_drop(self.softmax(self.matmul1([q, k]) * self.scale))
+            self.save_attn(attn)
+            if attn.requires_grad:
+                attn.register_hook(self.save_attn_gradients)
+            out = self.matmul2([attn, v]).permute(0, 2, 1, 3).reshape(B, N, C)  # 'b h n d -> b n (h d)'
+            return self.proj_drop(self.proj(out))
+
+        def relprop(self, cam, **kwargs):
+            """ViT_LRP.py:154-177."""
+            cam = self.proj.relprop(cam, **kwargs)
+            B, N, C = cam.shape
+            H = self.num_heads
+            D = C // H
+            r_heads = cam.view(B, N, H, D).permute(0, 2, 1, 3)                  # strided view, no copy
+            attn, v = self.matmul2.X
+            q, k = self.matmul1.X
+            cam_qkv = torch.empty((B, N, 3 * C), dtype=cam.dtype, device=cam.device)
+            slots = cam_qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)          # [3][B,H,N,D] views
+            var = self.matmul2.variant
+            cam1, cam_v = ops.matmul_relprop_av(r_heads, attn, v, out_scale=0.5, cam_v_out=slots[2], variant=var)
+            self.save_v_cam(cam_v)
+            self.save_attn_cam(cam1)
+            ops.matmul_relprop_qk(cam1, q, k, out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1], variant=var)
+            return self.qkv.relprop(cam_qkv, **kwargs)
+
+    class Block(nn.Module):
+        def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0.):
+            super().__init__()
+            self.norm1 = L.LayerNorm(dim, eps=1e-6)
+            self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+            self.norm2 = L.LayerNorm(dim, eps=1e-6)
+            self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
+            self.add1 = L.Add()
+            self.add2 = L.Add()
+            self.clone1 = L.Clone()
+            self.clone2 = L.Clone()
+
+        def forward(self, x):
+            x1, x2 = self.clone1(x, 2)
+            x = self.add1([x1, self.attn(self.norm1(x2))])
+            x1, x2 = self.clone2(x, 2)
+            return self.add2([x1, self.mlp(self.norm2(x2))])
+
+        def relprop(self, cam, **kwargs):
+            """ViT_LRP.py:203-213 (LayerNorm rules are the identity)."""
+            cam1, cam2 = self.add2.relprop(cam, **kwargs)
+            cam2 = self.mlp.relprop(cam2, **kwargs)
+            cam = self.clone2.relprop((cam1, cam2), **kwargs)
+            cam1, cam2 = self.add1.relprop(cam, **kwargs)
+            cam2 = self.attn.relprop(cam2, **kwargs)
+            return self.clone1.relprop((cam1, cam2), **kwargs)
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+            super().__init__()
+            img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+            patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+            self.img_size, self.patch_size = img_size, patch_size
+            self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0])
+            self.proj = L.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+        def forward(self, x):
+            B, C, Hh, Ww = x.shape
+            assert Hh == self.img_size[0] and Ww == self.img_size[1], \
+                f"Input image size ({Hh}*{Ww}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+        def relprop(self, cam, **kwargs):
+            cam = cam.transpose(1, 2)
+            cam = cam.reshape(cam.shape[0], cam.shape[1], self.img_size[0] // self.patch_size[0],
+                              self.img_size[1] // self.patch_size[1])
+            return self.proj.relprop(cam, **kwargs)
+
+    class VisionTransformer(nn.Module):
+        default_method = "transformer_attribution" if L.RelProp.variant == "ours" else "grad"
+
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                     num_heads=12, mlp_ratio=4., qkv_bias=False, mlp_head=False, drop_rate=0., attn_drop_rate=0.):
+            super().__init__()
+            self.num_classes = num_classes
+            self.num_features = self.embed_dim = embed_dim
+            self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                          embed_dim=embed_dim)
+            num_patches = self.patch_embed.num_patches
+            self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            self.blocks = nn.ModuleList([
+                Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                      attn_drop=attn_drop_rate) for _ in range(depth)])
+            self.norm = L.LayerNorm(embed_dim)
+            self.head = Mlp(embed_dim, int(embed_dim * mlp_ratio), num_classes) if mlp_head \
+                else L.Linear(embed_dim, num_classes)
+            _trunc_normal_(self.pos_embed, std=.02)
+            _trunc_normal_(self.cls_token, std=.02)
+            self.apply(self._init_weights)
+            self.pool = L.IndexSelect()
+            self.add = L.Add()
+            self.inp_grad = None
+
+        def save_inp_grad(self, grad): self.inp_grad = grad
+        def get_inp_grad(self): return self.inp_grad
+
+        def _init_weights(self, m):
+            if isinstance(m, nn.Linear):
+                _trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+        @property
+        def no_weight_decay(self):
+            return {'pos_embed', 'cls_token'}
+
+        def forward(self, x):
+            B = x.shape[0]
+            x = self.patch_embed(x)
+            x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
+            x = self.add([x, self.pos_embed])
+            if x.requires_grad:
+                x.register_hook(self.save_inp_grad)
+            for blk in self.blocks:
+                x = blk(x)
+            x = self.norm(x)
+            x = self.pool(x, dim=1, indices=torch.tensor(0, device=x.device)).squeeze(1)
+            return self.head(x)
+
+        # ------------------------------------------------------------------------------------------
+        def relprop(self, cam=None, method=None, is_ablation=False, start_layer=0, **kwargs):
+            """ViT_LRP.py:324-398.  cam: one-hot [B, num_classes]; returns per-sample maps."""
+            if method is None:
+                method = self.default_method
+            cam = self.head.relprop(cam, **kwargs)
+            cam = self.pool.relprop(cam.unsqueeze(1), **kwargs)
+            for blk in reversed(self.blocks):
+                cam = blk.relprop(cam, **kwargs)
+
+            if method == "full":
+                raise NotImplementedError("method='full' (Conv2d z^B rule) is off the accelerated hot path")
+
+            if method == "rollout":
+                mats = [blk.attn.get_attn_cam().clamp(min=0).mean(dim=1) for blk in self.blocks]
+                return compute_rollout_attention(mats, start_layer=start_layer)[:, 0, 1:]
+
+            if method in ("transformer_attribution", "grad"):
+                # ViT_LRP.py:357-369: per block mean_h max(grad * attn_cam, 0), then rollout, row 0
+                first = self.blocks[0].attn.get_attn_cam()
+                Bn, _, N, _ = first.shape
+                stack = torch.empty((len(self.blocks), Bn, N, N), dtype=first.dtype, device=first.device)
+                for i, blk in enumerate(self.blocks):
+                    ops.gradcam_headmean(blk.attn.get_attn_gradients(), blk.attn.get_attn_cam(), out=stack[i])
+                joint = ops.rollout(stack, start_layer=start_layer, normalise=False)
+                return joint[:, 0, 1:]
+
+            if method in ("last_layer", "second_layer"):
+                blk = self.blocks[-1] if method == "last_layer" else self.blocks[1]
+                c = blk.attn.get_attn_cam()
+                if is_ablation:
+                    c = blk.attn.get_attn_gradients() * c
+                return c.clamp(min=0).mean(dim=1)[:, 0, 1:]
+
+            if method == "last_layer_attn":
+                return self.blocks[-1].attn.get_attn().clamp(min=0).mean(dim=1)[:, 0, 1:]
+            return None   # unknown method: the reference falls through silently
+
+    def vit_base_patch16_224(pretrained=False, **kwargs):
+        if pretrained:
+            raise RuntimeError("no network: load a checkpoint with model.load_state_dict(...)")
+        return VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                                 **kwargs)
+
+    def vit_large_patch16_224(pretrained=False, **kwargs):
+        if pretrained:
+            raise RuntimeError("no network: load a checkpoint with model.load_state_dict(...)")
+        return VisionTransformer(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
+                                 **kwargs)
+
+    def deit_base_patch16_224(pretrained=False, **kwargs):
+        return vit_base_patch16_224(pretrained=pretrained, **kwargs)
+
+    ns = dict(Mlp=Mlp, Attention=Attention, Block=Block, PatchEmbed=PatchEmbed, VisionTransformer=VisionTransformer,
+              vit_base_patch16_224=vit_base_patch16_224, vit_large_patch16_224=vit_large_patch16_224,
+              deit_base_patch16_224=deit_base_patch16_224)
+    return ns
+
+
+_ns = make_vit_module(R_ours)
+Mlp, Attention, Block, PatchEmbed = _ns["Mlp"], _ns["Attention"], _ns["Block"], _ns["PatchEmbed"]
+VisionTransformer = _ns["VisionTransformer"]
+vit_base_patch16_224 = _ns["vit_base_patch16_224"]
+vit_large_patch16_224 = _ns["vit_large_patch16_224"]
+deit_base_patch16_224 = _ns["deit_base_patch16_224"]
