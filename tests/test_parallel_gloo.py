@@ -1,0 +1,78 @@
+"""Multi-process path on CPU: world_size-2 `gloo` run of the shard -> explain -> gather pipeline
+(transformer_explainability_amd/parallel.py).  The per-rank "explain" step is the real host path (our
+ViT + generators) with the device ops routed to the oracle, so the test checks that any shard layout
+reproduces the single-process maps bit for bit and in global order."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _explain(indices):
+    from oracle_backend import oracle_ops
+    from transformer_explainability_amd import parallel, vit
+    from transformer_explainability_amd.generators import LRP
+    torch.manual_seed(0)
+    model = vit.VisionTransformer(img_size=32, patch_size=8, embed_dim=32, depth=2, num_heads=2, num_classes=5,
+                                  qkv_bias=True).eval()
+    x = torch.stack([parallel.synthetic_image(i, (3, 32, 32)) for i in indices])
+    with oracle_ops():
+        # one sample at a time so that the forward GEMM shapes (and rounding) do not depend on the shard size
+        return torch.cat([LRP(model).generate_LRP(x[i:i + 1], start_layer=0).detach() for i in range(len(indices))])
+
+
+def _worker(rank, world, port, n_items, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from transformer_explainability_amd import parallel
+    r, w, _ = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    idx = list(parallel.shard_indices(n_items, r, w))
+    local = _explain(idx)
+    full = parallel.gather_maps(local, n_items)
+    torch.save({"full": full, "idx": idx}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_ranges_cover_everything():
+    from transformer_explainability_amd import parallel
+    for n in (1, 5, 8, 50000):
+        for world in (1, 2, 3, 8):
+            ranges = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+                assert a1 == b0 and a1 >= a0
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_matches_single_process(tmp_path):
+    n_items = 5      # odd on purpose: ranks own 3 and 2 samples (ragged shards)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    single = _explain(list(range(n_items)))
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_items, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        got = torch.load(os.path.join(str(tmp_path), f"rank{rank}.pt"))
+        assert got["full"].shape == single.shape
+        assert torch.equal(got["full"], single), f"rank {rank}: gathered maps differ from the single-process run"
+    assert torch.load(os.path.join(str(tmp_path), "rank0.pt"))["idx"] == [0, 1, 2]
+    assert torch.load(os.path.join(str(tmp_path), "rank1.pt"))["idx"] == [3, 4]
