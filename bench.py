@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import argparse
 import contextlib
+import faulthandler
 import json
 import os
 import sys
@@ -37,6 +38,29 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress to stderr (the JSON line is the only thing on stdout)."""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually run on (cgroup / affinity aware), capped: torch CPU GEMMs stop scaling
+    long before a 100+ core host is filled and oversubscribing a container quota is catastrophic."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:   # cgroup v2 CPU quota
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
 
 
 class KernelTimer:
@@ -71,8 +95,9 @@ class KernelTimer:
 def cpu_baseline(args, model_cpu_state, n_maps=3):
     """Time the CPU path on this box's host cores: one sample at a time (the reference is batch-1)."""
     from oracle import ref_harness as rh
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads (os.cpu_count() = {os.cpu_count()})")
     x = torch.stack([synthetic_image(i) for i in range(n_maps + 1)])
     if rh.reference_available() and args.cpu_baseline != "port":
         mods = rh.load_reference_vit()
@@ -84,6 +109,7 @@ def cpu_baseline(args, model_cpu_state, n_maps=3):
             t0 = time.perf_counter()
             gen.generate_LRP(x[i:i + 1], method="transformer_attribution", start_layer=args.start_layer)
             times.append(time.perf_counter() - t0)
+            log(f"cpu_baseline(reference) map {i}: {times[-1]:.2f} s")
         kind = "reference"
     else:
         from transformer_explainability_amd import vit
@@ -102,6 +128,7 @@ def cpu_baseline(args, model_cpu_state, n_maps=3):
                 b.attn.save_attn_gradients(g)
             O.vit_relprop(oh, vit_cache_from_model(model), num_heads=12, start_layer=args.start_layer)
             times.append(time.perf_counter() - t0)
+            log(f"cpu_baseline(port) map {i}: {times[-1]:.2f} s")
         kind = "port"
     times = sorted(times[1:])
     med = times[len(times) // 2]
@@ -125,6 +152,8 @@ def main():
     ap.add_argument("--cpu-baseline", choices=["auto", "port", "off"], default="auto")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)   # a stuck run leaves a stack trace
 
     import __graft_entry__
     import transformer_explainability_amd as te
@@ -152,6 +181,7 @@ def main():
     B = args.batch
     x = torch.stack([synthetic_image(rank * B + i) for i in range(B)]).to(dev)
     lrp = LRP(model)
+    log(f"rank {rank}/{world}: model + {B} images resident on {dev}")
 
     timer = KernelTimer()
     if not args.no_roofline:
@@ -160,8 +190,10 @@ def main():
     def step():
         return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
         maps = step()
+        torch.cuda.synchronize()
+        log(f"warmup step {w} done")
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -176,6 +208,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log(f"timed {args.steps} steps: {elapsed:.3f} s")
     timer.enabled = False
     ops.KERNEL_TIMER = None
     if world > 1:
@@ -213,6 +246,7 @@ def main():
             base = cpu_baseline(args, cpu_state)
         line["cpu_baseline"] = base
         print(json.dumps(line), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -42,6 +42,24 @@ def check(name, got, ref, rel_tol, exact=False):
     return s
 
 
+def check_conditioned(name, got, ref32, ref64, base_tol, k=20.0):
+    """Conditioning-aware comparison for rules that divide by a mixed-sign sum (safe_divide(R, Z) with
+    Z = sum of products of either sign): the fp32 oracle itself is only accurate to its own distance
+    from the fp64 oracle on such inputs, so the bar for the HIP result is
+        max|got - ref64| <= k * max|ref32 - ref64| + base_tol * max|ref64|
+    i.e. "as accurate as a plain fp32 evaluation in a different summation order"."""
+    got = got.detach().cpu().double()
+    ref32, ref64 = ref32.detach().cpu().double(), ref64.detach().cpu().double()
+    err = float((got - ref64).abs().max())
+    floor = float((ref32 - ref64).abs().max())
+    mx = float(ref64.abs().max())
+    tol = k * floor + base_tol * mx
+    record(name, max_abs_vs_fp64=err, oracle32_vs_fp64=floor, ref_max=mx, rel=err / max(mx, 1e-30), tol_abs=tol,
+           nonfinite=int((~torch.isfinite(got)).sum()))
+    assert torch.isfinite(got).all(), name
+    assert err <= tol, (name, dict(err=err, floor=floor, ref_max=mx, tol=tol))
+
+
 from oracle.model_cache import bert_cache_from_model, vit_cache_from_model  # noqa: E402,F401
 
 
@@ -57,3 +75,59 @@ def map_stats(got, ref):
     raw = float((got - ref).abs().max())
     return {"raw_max_abs": raw, "normalised_max_abs": float((minmax(got) - minmax(ref)).abs().max()),
             "rel_linf": raw / max(float(ref.abs().max()), 1e-30), "ref_max": float(ref.abs().max())}
+
+
+def _move(v, device):
+    if torch.is_tensor(v):
+        return v.to(device)
+    if isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
+        return type(v)(t.to(device) for t in v)
+    return v
+
+
+def move_relprop_state(model, device):
+    """Move every tensor the relprop path reads from module attributes (self.X / self.Y of the rule
+    modules, cached attention probabilities / gradients / masks) to `device`, together with the
+    parameters.  Lets a test produce the caches with the CPU forward + backward (bit-comparable to the
+    reference's CPU producers) and then run the HIP relprop on exactly those tensors."""
+    for m in model.modules():
+        for name, val in list(vars(m).items()):
+            if name.startswith("_"):
+                continue
+            new = _move(val, device)
+            if new is not val:
+                setattr(m, name, new)
+    model.to(device)
+    return model
+
+
+class sliced_relprop_state:
+    """Context manager: temporarily replace every cached tensor with leading dimension `B` (module attributes
+    X / Y / attn / gradients / masks) by its slice [i:i+1], so that relprop runs on sample i alone -- on exactly
+    the tensors the batched run consumed."""
+
+    def __init__(self, model, i, B):
+        self.model, self.i, self.B = model, i, B
+        self.saved = []
+
+    def _slice(self, v):
+        if torch.is_tensor(v) and v.dim() >= 2 and v.shape[0] == self.B:
+            return v[self.i:self.i + 1]
+        if isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
+            return type(v)(self._slice(t) for t in v)
+        return v
+
+    def __enter__(self):
+        for m in self.model.modules():
+            for name, val in list(vars(m).items()):
+                if name.startswith("_"):
+                    continue
+                new = self._slice(val)
+                if new is not val:
+                    self.saved.append((m, name, val))
+                    setattr(m, name, new)
+        return self
+
+    def __exit__(self, *a):
+        for m, name, val in self.saved:
+            setattr(m, name, val)

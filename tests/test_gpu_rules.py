@@ -5,7 +5,7 @@ level); GEMM-carrying rules differ only by fp32 summation order (relative 2e-5 o
 import pytest
 import torch
 
-from gpu_util import check, dev, record, rnd
+from gpu_util import check, check_conditioned, dev, record, rnd
 from oracle import relprop_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -165,21 +165,29 @@ def test_linear_rows_independent_and_homogeneous():
 
 # ------------------------------------------------------------------------------------------ attention rules
 @pytest.mark.parametrize("simple", [False, True], ids=["tiled", "simple"])
-@pytest.mark.parametrize("B,H,N,D", [(2, 3, 7, 8), (2, 12, 197, 64), (1, 4, 130, 64), (1, 2, 577, 64)])
-def test_attention_rules_fused_qkv_layout(simple, B, H, N, D):
+@pytest.mark.parametrize("signed", [False, True], ids=["positive", "mixedsign"])
+@pytest.mark.parametrize("B,H,N,D", [(2, 3, 7, 8), (2, 12, 197, 64), (1, 4, 130, 64), (1, 2, 577, 64), (4, 12, 197, 64),
+                                     (1, 2, 64, 64), (1, 1, 65, 64), (2, 2, 512, 64), (1, 3, 33, 32)])
+def test_attention_rules_fused_qkv_layout(simple, signed, B, H, N, D):
     """q/k/v read in place from the fused qkv activation [B,N,3HD]; outputs written in place into the
-    'b n (qkv h d)' relevance buffer (strided views)."""
+    'b n (qkv h d)' relevance buffer (strided views).
+
+    positive : q, k, v > 0 => every Z = sum of positive products is well conditioned, so the kernels must
+               agree with the fp32 oracle to summation-order accuracy (3e-5 of the tensor max).
+    mixedsign: Z = attn v and Z = q k^T change sign, sd(R, Z) is ill conditioned wherever Z ~ 0 and the
+               fp32 oracle itself is only as accurate as its distance to the fp64 oracle; the kernels are
+               held to that band (gpu_util.check_conditioned)."""
     from transformer_explainability_amd import ops
     set_impl(simple)
     C = H * D
     qkv = rnd((B, N, 3 * C), 31)
+    if not signed:
+        qkv = qkv.abs() + 0.05
     v5 = qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
     q, k, v = v5[0], v5[1], v5[2]
     attn = torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1).contiguous()
     Rav = rnd((B, N, C), 32, 0.01)
     r_heads = Rav.view(B, N, H, D).permute(0, 2, 1, 3)
-    ref_attn, ref_v = O.einsum_av_relprop(r_heads, attn, v)
-    ref_q, ref_k = O.einsum_qk_relprop(ref_attn * 0.5, q, k)
 
     d = dev()
     qkv_d = qkv.to(d)
@@ -189,12 +197,45 @@ def test_attention_rules_fused_qkv_layout(simple, B, H, N, D):
     cam1, cam_v = ops.matmul_relprop_av(Rav.to(d).view(B, N, H, D).permute(0, 2, 1, 3), attn.to(d), v5d[2],
                                         out_scale=0.5, cam_v_out=slots[2])
     ops.matmul_relprop_qk(cam1, v5d[0], v5d[1], out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1])
-    tag = f"({B},{H},{N},{D}){'simple' if simple else 'tiled'}"
-    check("av.cam_attn" + tag, cam1, ref_attn * 0.5, 3e-5)
-    check("av.cam_v" + tag, slots[2], ref_v * 0.5, 3e-5)
-    check("qk.cam_q" + tag, slots[0], ref_q * 0.5, 3e-5)
-    check("qk.cam_k" + tag, slots[1], ref_k * 0.5, 3e-5)
     assert not torch.isnan(cam_qkv).any()       # every slot of the fused buffer was written
+
+    # the QK rule is checked on the relevance the device AV rule produced (its own input), so that each
+    # rule is compared on identical inputs
+    cam1_c = cam1.cpu()
+    tag = f"({B},{H},{N},{D}){'simple' if simple else 'tiled'}{'+-' if signed else '+'}"
+    ref_attn, ref_v = O.einsum_av_relprop(r_heads, attn, v)
+    ref_q, ref_k = O.einsum_qk_relprop(cam1_c, q, k)
+    if not signed:
+        check("av.cam_attn" + tag, cam1, ref_attn * 0.5, 3e-5)
+        check("av.cam_v" + tag, slots[2], ref_v * 0.5, 3e-5)
+        check("qk.cam_q" + tag, slots[0], ref_q * 0.5, 3e-5)
+        check("qk.cam_k" + tag, slots[1], ref_k * 0.5, 3e-5)
+    else:
+        a64, v64 = O.einsum_av_relprop(r_heads.double(), attn.double(), v.double())
+        q64, k64 = O.einsum_qk_relprop(cam1_c.double(), q.double(), k.double())
+        check_conditioned("av.cam_attn" + tag, cam1, ref_attn * 0.5, a64 * 0.5, 3e-5)
+        check_conditioned("av.cam_v" + tag, slots[2], ref_v * 0.5, v64 * 0.5, 3e-5)
+        check_conditioned("qk.cam_q" + tag, slots[0], ref_q * 0.5, q64 * 0.5, 3e-5)
+        check_conditioned("qk.cam_k" + tag, slots[1], ref_k * 0.5, k64 * 0.5, 3e-5)
+
+
+def test_attention_rules_batch_independent():
+    """(b,h) problems are independent: a batch run equals per-sample runs bitwise (full ViT-B geometry)."""
+    from transformer_explainability_amd import ops
+    B, H, N, D = 3, 12, 197, 64
+    C = H * D
+    d = dev()
+    qkv = rnd((B, N, 3 * C), 33).to(d)
+    v5 = qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    attn = torch.softmax(v5[0] @ v5[1].transpose(-1, -2) * D ** -0.5, -1).contiguous()
+    R = rnd((B, H, N, D), 34, 0.01).to(d)
+    cam1, cam_v = ops.matmul_relprop_av(R, attn, v5[2], out_scale=0.5)
+    cam_q, cam_k = ops.matmul_relprop_qk(cam1, v5[0], v5[1], out_scale=0.5)
+    for i in range(B):
+        c1, cv = ops.matmul_relprop_av(R[i:i + 1], attn[i:i + 1], v5[2][i:i + 1], out_scale=0.5)
+        cq, ck = ops.matmul_relprop_qk(c1, v5[0][i:i + 1], v5[1][i:i + 1], out_scale=0.5)
+        assert torch.equal(c1, cam1[i:i + 1]) and torch.equal(cv, cam_v[i:i + 1])
+        assert torch.equal(cq, cam_q[i:i + 1]) and torch.equal(ck, cam_k[i:i + 1])
 
 
 # ------------------------------------------------------------------------------------------ rollout
@@ -226,12 +267,16 @@ def test_golden_rules(golden_rules):
                                variant=variant)
         check(f"golden.add_{variant}.a", a, g[f"add_{variant}.out0"], 2e-5)
         check(f"golden.add_{variant}.b", b, g[f"add_{variant}.out1"], 2e-5)
+    # the golden attention inputs are mixed-sign (Z ~ 0 somewhere): reference outputs vs their fp64 restatement
+    # give the accuracy band of a plain fp32 evaluation (gpu_util.check_conditioned)
     o0, o1 = ops.matmul_relprop_av(g["av.R"].to(d), g["av.attn"].to(d), g["av.v"].to(d))
-    check("golden.av.out0", o0, g["av.out0"], 2e-5)
-    check("golden.av.out1", o1, g["av.out1"], 2e-5)
+    r0, r1 = O.einsum_av_relprop(g["av.R"].double(), g["av.attn"].double(), g["av.v"].double())
+    check_conditioned("golden.av.out0", o0, g["av.out0"], r0, 2e-5)
+    check_conditioned("golden.av.out1", o1, g["av.out1"], r1, 2e-5)
     o0, o1 = ops.matmul_relprop_qk(g["qk.R"].to(d), g["qk.q"].to(d), g["qk.k"].to(d))
-    check("golden.qk.out0", o0, g["qk.out0"], 2e-5)
-    check("golden.qk.out1", o1, g["qk.out1"], 2e-5)
+    r0, r1 = O.einsum_qk_relprop(g["qk.R"].double(), g["qk.q"].double(), g["qk.k"].double())
+    check_conditioned("golden.qk.out0", o0, g["qk.out0"], r0, 2e-5)
+    check_conditioned("golden.qk.out1", o1, g["qk.out1"], r1, 2e-5)
     a, b = ops.add_relprop(g["add_mask.R"].to(d), g["add_mask.X0"].to(d), g["add_mask.X1"].to(d))
     check("golden.add_mask.a", a, g["add_mask.out0"], 2e-5)
     for num in (2, 3):
@@ -260,13 +305,15 @@ def test_rule_modules_match_reference_api(golden_rules):
     e2 = rules.einsum('bhij,bhjd->bhid')
     e2([g["av.attn"].to(d), g["av.v"].to(d)])
     o0, o1 = e2.relprop(g["av.R"].to(d), 1)
-    check("module.einsum_av.0", o0, g["av.out0"], 2e-5)
-    check("module.einsum_av.1", o1, g["av.out1"], 2e-5)
+    r0, r1 = O.einsum_av_relprop(g["av.R"].double(), g["av.attn"].double(), g["av.v"].double())
+    check_conditioned("module.einsum_av.0", o0, g["av.out0"], r0, 2e-5)
+    check_conditioned("module.einsum_av.1", o1, g["av.out1"], r1, 2e-5)
     mm = rules.MatMul()
     mm([g["qk.q"].to(d), g["qk.k"].to(d).transpose(-1, -2)])
     o0, o1 = mm.relprop(g["qk.R"].to(d), 1)
-    check("module.matmul_qkT.0", o0, g["matmul_qkT.out0"], 2e-5)
-    check("module.matmul_qkT.1", o1, g["matmul_qkT.out1"], 2e-5)
+    r0, r1 = O.matmul_relprop(g["qk.R"].double(), g["qk.q"].double(), g["qk.k"].double().transpose(-1, -2))
+    check_conditioned("module.matmul_qkT.0", o0, g["matmul_qkT.out0"], r0, 2e-5)
+    check_conditioned("module.matmul_qkT.1", o1, g["matmul_qkT.out1"], r1, 2e-5)
     cl = rules.Clone()
     cl(g["clone3.X"].to(d), 3)
     check("module.clone3", cl.relprop([g[f"clone3.R{i}"].to(d) for i in range(3)], 1), g["clone3.out"], 1e-6)

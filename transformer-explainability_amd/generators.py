@@ -72,7 +72,12 @@ class Generator:
         return layers
 
     def generate_LRP(self, input_ids, attention_mask, index=None, start_layer=11):
-        layers = self._explain(input_ids, attention_mask, index)
+        self._explain(input_ids, attention_mask, index)
+        return self.attribution_tail(start_layer)
+
+    def attribution_tail(self, start_layer=11):
+        """ExplanationGenerator.py:47-59 on the attn_cam / attention gradients cached by relprop + backward."""
+        layers = self.model.bert.encoder.layer
         first = layers[0].attention.self.get_attn_cam()
         B, _, N, _ = first.shape
         stack = torch.empty((len(layers), B, N, N), dtype=first.dtype, device=first.device)
