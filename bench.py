@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--start-layer", type=int, default=1)
     ap.add_argument("--cpu-baseline", choices=["auto", "port", "off"], default="auto")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="micro-batches in flight on separate HIP streams")
     args = ap.parse_args()
     faulthandler.enable()
     faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)   # a stuck run leaves a stack trace
@@ -180,7 +181,7 @@ def main():
     model.to(dev)
     B = args.batch
     x = torch.stack([synthetic_image(rank * B + i) for i in range(B)]).to(dev)
-    lrp = LRP(model)
+    lrp = LRP(model, streams=args.streams)
     log(f"rank {rank}/{world}: model + {B} images resident on {dev}")
 
     timer = KernelTimer()
@@ -227,7 +228,7 @@ def main():
             "config": {"workload": "ViT-B/16 224^2 batch 64 on 1xMI355X: stock fwd + attn-grad bwd + fp32 relprop/"
                                    "head-mean/rollout HIP kernels (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": 197, "blocks": 12,
-                       "start_layer": args.start_layer, "parallelism": f"dp{world} (independent samples, one "
+                       "start_layer": args.start_layer, "streams": args.streams, "parallelism": f"dp{world} (independent samples, one "
                                                                       f"all_gather of the maps)"},
         }
         roof = None

@@ -225,6 +225,17 @@ def test_vit_b16_batch_equals_singles(vit_b16):
             assert torch.equal(one, batch[i:i + 1]), f"sample {i}: batched relprop != per-sample relprop on the same cache"
             for l, blk in enumerate(model.blocks):
                 assert torch.equal(blk.attn.get_attn_cam(), cams[l][i:i + 1]), (i, l)
+    # exact class-token sparsity shortcut of the last block (vit.Block.relprop_cls_only) == dense evaluation, bitwise
+    model.exploit_cls_sparsity = False
+    dense = model.relprop(oh, method="transformer_attribution", start_layer=1, alpha=1)
+    model.exploit_cls_sparsity = True
+    assert torch.equal(dense, batch), float((dense - batch).abs().max())
+    for l, blk in enumerate(model.blocks):
+        assert torch.equal(blk.attn.get_attn_cam(), cams[l]), l
+    # micro-batches on separate HIP streams == the same micro-batches run one after the other, bitwise
+    streamed = LRP(model, streams=2).generate_LRP(x, start_layer=1)
+    halves = torch.cat([lrp.generate_LRP(x[:2], start_layer=1), lrp.generate_LRP(x[2:], start_layer=1)], 0)
+    assert torch.equal(streamed, halves), float((streamed - halves).abs().max())
     singles = torch.cat([lrp.generate_LRP(x[i:i + 1], start_layer=1) for i in range(B)], 0)
     _assert_map("vit_b16.batch_vs_separate_forwards", batch, singles, **LOOSE)
     # LRP conservation: the token relevance of every sample sums to 1

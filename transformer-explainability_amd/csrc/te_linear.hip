@@ -25,14 +25,19 @@
 //
 // Odd shapes (in_f or out_f not a multiple of 4, or forced by TE_IMPL_SIMPLE) use plain one-thread-
 // per-output kernels; they double as the on-device cross-check for the tiled path.
+#include <stdlib.h>
+
 #include "te_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BK = 32;
 constexpr int LDT = BK + 4;       // padded leading dim of K-contiguous tiles (floats)
-constexpr int LDBN = BN;          // leading dim of the K2 B tile [BK][BN]
 constexpr int kThreads = 256;
+// The block tile is BM x BN with BN = 128 (each wave 64 x 64 = 2 x 2 MFMA blocks) or BN = 64 (each wave 64 x 32 =
+// 2 x 1).  fp32 MFMA is 16x slower than bf16 MFMA, so even the narrow tile leaves LDS / L2 bandwidth idle; what it
+// buys is granularity: a 12,608 x 768 output is 594 wide tiles = 2.32 per CU (a third round that is 1/3 full),
+// but 1188 narrow tiles = 4.64 per CU.  pick_bn() chooses per launch.
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   // bijective remap: XCD x (= bid % 8 by dispatch order) gets a contiguous run of logical tiles
@@ -42,11 +47,12 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   return base + idx;
 }
 
-// Stage a [128 rows][32 k] tile of a K-contiguous matrix M (ld = K) into registers (4 x float4/thread).
+// Stage a [ROWS rows][32 k] tile of a K-contiguous matrix M (ld = K) into registers (ROWS/32 x float4/thread).
+template <int ROWS>
 __device__ __forceinline__ void load_rows_tile(const float* __restrict__ M, int64_t rows, int64_t K,
-                                               int64_t row0, int64_t k0, f32x4 (&reg)[4]) {
+                                               int64_t row0, int64_t k0, f32x4 (&reg)[ROWS / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < ROWS / 32; ++i) {
     const int idx = threadIdx.x + i * kThreads;  // 0..1023
     const int row = idx >> 3, c4 = idx & 7;
     const int64_t gr = row0 + row, gk = k0 + c4 * 4;
@@ -55,33 +61,36 @@ __device__ __forceinline__ void load_rows_tile(const float* __restrict__ M, int6
     reg[i] = v;
   }
 }
-__device__ __forceinline__ void store_rows_tile(float* __restrict__ lds, const f32x4 (&reg)[4]) {
+template <int ROWS>
+__device__ __forceinline__ void store_rows_tile(float* __restrict__ lds, const f32x4 (&reg)[ROWS / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < ROWS / 32; ++i) {
     const int idx = threadIdx.x + i * kThreads;
     const int row = idx >> 3, c4 = idx & 7;
     *reinterpret_cast<f32x4*>(lds + row * LDT + c4 * 4) = reg[i];
   }
 }
-// Stage a [32 k][128 n] tile of a row-major K x N matrix (ld = Nn).
+// Stage a [32 k][BN n] tile of a row-major K x N matrix (ld = Nn).
+template <int BN>
 __device__ __forceinline__ void load_kn_tile(const float* __restrict__ M, int64_t K, int64_t Nn,
-                                             int64_t k0, int64_t n0, f32x4 (&reg)[4]) {
+                                             int64_t k0, int64_t n0, f32x4 (&reg)[BN / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BN / 32; ++i) {
     const int idx = threadIdx.x + i * kThreads;
-    const int kk = idx >> 5, c4 = idx & 31;
+    const int kk = idx / (BN / 4), c4 = idx % (BN / 4);
     const int64_t gk = k0 + kk, gn = n0 + c4 * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (gk < K && gn < Nn) v = *reinterpret_cast<const f32x4*>(M + gk * Nn + gn);
     reg[i] = v;
   }
 }
-__device__ __forceinline__ void store_kn_tile(float* __restrict__ lds, const f32x4 (&reg)[4]) {
+template <int BN>
+__device__ __forceinline__ void store_kn_tile(float* __restrict__ lds, const f32x4 (&reg)[BN / 32]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BN / 32; ++i) {
     const int idx = threadIdx.x + i * kThreads;
-    const int kk = idx >> 5, c4 = idx & 31;
-    *reinterpret_cast<f32x4*>(lds + kk * LDBN + c4 * 4) = reg[i];
+    const int kk = idx / (BN / 4), c4 = idx % (BN / 4);
+    *reinterpret_cast<f32x4*>(lds + kk * BN + c4 * 4) = reg[i];
   }
 }
 
@@ -91,12 +100,15 @@ __device__ __forceinline__ void store_kn_tile(float* __restrict__ lds, const f32
 // K1: S = sd(R, X+ W+^T + X- W-^T)        SWAP exchanges W+ / W- (inhibitor term, beta != 0)
 //     LRP: S1 = sd(R, X+ W+^T), S2 = sd(R, X- W-^T) kept apart (layers_lrp.py:199-200)
 // ------------------------------------------------------------------------------------------------
-template <bool LRP, bool SWAP>
+template <bool LRP, bool SWAP, int BN>
 __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ R,
     float* __restrict__ S1, float* __restrict__ S2, int64_t T, int64_t K, int64_t Nn, int nbn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int STAGE = 2 * BM * LDT;  // floats per pipeline stage: [A tile | B tile]
+  constexpr int NI = BN / 64;                 // 32-wide MFMA column blocks per wave
+  constexpr int WN = BN / 2;                  // columns per wave
+  constexpr int A_SZ = BM * LDT;
+  constexpr int STAGE = (BM + BN) * LDT;      // floats per pipeline stage: [A tile | B tile]
 
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const int64_t row0 = (int64_t)(tile / nbn) * BM;
@@ -106,49 +118,49 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
   const int lr = lane & 31, kh = lane >> 5;
 
   constexpr int NACC = LRP ? 2 : 1;
-  f32x16 acc[NACC][2][2];
+  f32x16 acc[NACC][2][NI];
 #pragma unroll
   for (int s = 0; s < NACC; ++s)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][mi][ni][e] = 0.0f;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[BM / 32], rb[BN / 32];
   const int nk = (int)((K + BK - 1) / BK);
-  load_rows_tile(X, T, K, row0, 0, ra);
-  load_rows_tile(W, Nn, K, col0, 0, rb);
-  store_rows_tile(smem, ra);
-  store_rows_tile(smem + BM * LDT, rb);
+  load_rows_tile<BM>(X, T, K, row0, 0, ra);
+  load_rows_tile<BN>(W, Nn, K, col0, 0, rb);
+  store_rows_tile<BM>(smem, ra);
+  store_rows_tile<BN>(smem + A_SZ, rb);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_rows_tile(X, T, K, row0, (int64_t)(kt + 1) * BK, ra);
-      load_rows_tile(W, Nn, K, col0, (int64_t)(kt + 1) * BK, rb);
+      load_rows_tile<BM>(X, T, K, row0, (int64_t)(kt + 1) * BK, ra);
+      load_rows_tile<BN>(W, Nn, K, col0, (int64_t)(kt + 1) * BK, rb);
     }
     const float* a_base = smem + cur * STAGE + (wm * 64 + lr) * LDT + kh * 4;
-    const float* b_base = smem + cur * STAGE + BM * LDT + (wn * 64 + lr) * LDT + kh * 4;
+    const float* b_base = smem + cur * STAGE + A_SZ + (wn * WN + lr) * LDT + kh * 4;
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
-      f32x4 a[2], b[2];
+      f32x4 a[2], b[NI];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a_base + mi * 32 * LDT + kg * 8);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b_base + ni * 32 * LDT + kg * 8);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b_base + ni * 32 * LDT + kg * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float ap[2], an[2], bp[2], bn[2];
+        float ap[2], an[2], bp[NI], bn[NI];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           ap[mi] = fmaxf(a[mi][j], 0.0f);
           an[mi] = fminf(a[mi][j], 0.0f);
         }
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           const float p = fmaxf(b[ni][j], 0.0f), n = fminf(b[ni][j], 0.0f);
           bp[ni] = SWAP ? n : p;   // partner of X+
           bn[ni] = SWAP ? p : n;   // partner of X-
@@ -156,17 +168,17 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[0][mi][ni] = TE_MFMA(ap[mi], bp[ni], acc[0][mi][ni]);
+          for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(ap[mi], bp[ni], acc[0][mi][ni]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
             acc[NACC - 1][mi][ni] = TE_MFMA(an[mi], bn[ni], acc[NACC - 1][mi][ni]);
       }
     }
     if (kt + 1 < nk) {
-      store_rows_tile(smem + (cur ^ 1) * STAGE, ra);
-      store_rows_tile(smem + (cur ^ 1) * STAGE + BM * LDT, rb);
+      store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
+      store_rows_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
     }
     __syncthreads();
   }
@@ -175,8 +187,8 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int64_t gc = col0 + wn * 64 + ni * 32 + lr;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t gc = col0 + wn * WN + ni * 32 + lr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t gr = row0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -199,12 +211,13 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 //     MODE 2: out += scale * X- . (S W(-))   (lrp second half, S = S2)
 //     SWAP exchanges W+ / W-.  ACCUM: out = out - scale * (...)   (the beta * inhibitor term)
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool SWAP, bool ACCUM>
+template <int MODE, bool SWAP, bool ACCUM, int BN>
 __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
     const float* __restrict__ S, const float* __restrict__ W, const float* __restrict__ X,
     float* __restrict__ out, int64_t T, int64_t K, int64_t Nn, int nbn, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int A_SZ = BM * LDT, B_SZ = BK * LDBN;
+  constexpr int NI = BN / 64, WN = BN / 2;
+  constexpr int A_SZ = BM * LDT, B_SZ = BK * BN;
   constexpr int STAGE = A_SZ + B_SZ;   // floats per pipeline stage: [A tile | B tile]
 
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -215,32 +228,32 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
   const int lr = lane & 31, kh = lane >> 5;
 
   constexpr int NACC = (MODE == 0) ? 2 : 1;
-  f32x16 acc[NACC][2][2];
+  f32x16 acc[NACC][2][NI];
 #pragma unroll
   for (int s = 0; s < NACC; ++s)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][mi][ni][e] = 0.0f;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[BM / 32], rb[BN / 32];
   const int nk = (int)((K + BK - 1) / BK);
-  load_rows_tile(S, T, K, row0, 0, ra);
-  load_kn_tile(W, K, Nn, 0, col0, rb);
-  store_rows_tile(smem, ra);
-  store_kn_tile(smem + A_SZ, rb);
+  load_rows_tile<BM>(S, T, K, row0, 0, ra);
+  load_kn_tile<BN>(W, K, Nn, 0, col0, rb);
+  store_rows_tile<BM>(smem, ra);
+  store_kn_tile<BN>(smem + A_SZ, rb);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_rows_tile(S, T, K, row0, (int64_t)(kt + 1) * BK, ra);
-      load_kn_tile(W, K, Nn, (int64_t)(kt + 1) * BK, col0, rb);
+      load_rows_tile<BM>(S, T, K, row0, (int64_t)(kt + 1) * BK, ra);
+      load_kn_tile<BN>(W, K, Nn, (int64_t)(kt + 1) * BK, col0, rb);
     }
     const float* a_base = smem + cur * STAGE + (wm * 64 + lr) * LDT + kh * 4;
-    const float* b_base = smem + cur * STAGE + A_SZ + (kh * 4) * LDBN + wn * 64 + lr;
+    const float* b_base = smem + cur * STAGE + A_SZ + (kh * 4) * BN + wn * WN + lr;
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       f32x4 a[2];
@@ -248,10 +261,10 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
       for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a_base + mi * 32 * LDT + kg * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float bp[2], bn[2];
+        float bp[NI], bn[NI];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const float w = b_base[(kg * 8 + j) * LDBN + ni * 32];
+        for (int ni = 0; ni < NI; ++ni) {
+          const float w = b_base[(kg * 8 + j) * BN + ni * 32];
           const float p = fmaxf(w, 0.0f), n = fminf(w, 0.0f);
           bp[ni] = SWAP ? n : p;
           bn[ni] = SWAP ? p : n;
@@ -260,20 +273,20 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[0][mi][ni] = TE_MFMA(a[mi][j], bp[ni], acc[0][mi][ni]);
+            for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(a[mi][j], bp[ni], acc[0][mi][ni]);
         }
         if constexpr (MODE == 0 || MODE == 2) {
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
               acc[NACC - 1][mi][ni] = TE_MFMA(a[mi][j], bn[ni], acc[NACC - 1][mi][ni]);
         }
       }
     }
     if (kt + 1 < nk) {
-      store_rows_tile(smem + (cur ^ 1) * STAGE, ra);
-      store_kn_tile(smem + (cur ^ 1) * STAGE + A_SZ, rb);
+      store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
+      store_kn_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
     }
     __syncthreads();
   }
@@ -281,8 +294,8 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int64_t gc = col0 + wn * 64 + ni * 32 + lr;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t gc = col0 + wn * WN + ni * 32 + lr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t gr = row0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -349,15 +362,54 @@ __global__ __launch_bounds__(kThreads) void linear_k2_simple(
   out[idx] = v;
 }
 
-constexpr size_t kK1Lds = (size_t)4 * BM * LDT * sizeof(float);                    // 73,728 B
-constexpr size_t kK2Lds = (size_t)2 * (BM * LDT + BK * LDBN) * sizeof(float);      // 69,632 B
+template <int BN>
+constexpr size_t k1_lds() { return (size_t)2 * (BM + BN) * LDT * sizeof(float); }          // 73,728 / 55,296 B
+template <int BN>
+constexpr size_t k2_lds() { return (size_t)2 * (BM * LDT + BK * BN) * sizeof(float); }      // 69,632 / 53,248 B
 
 template <typename Kern>
 inline void allow_lds(Kern kern, size_t bytes) {
   // > 64 KiB of dynamic LDS must be opted into; cheap and idempotent, no device state besides the
   // function attribute.
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes);
+  if (bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes);
+}
+
+// Tile-width choice per launch.  Work is issued in rounds of one tile per CU-slot; a launch whose tile count is
+// just above a multiple of the CU count wastes most of its last round.  Estimate the chip-level efficiency of
+// each width as (tiles / CUs) / ceil(tiles / CUs) -- times 0.96 for the narrow tile, whose B operand is re-staged
+// twice as often -- and take the better one.  TE_LINEAR_BN = 64 | 128 in the environment pins the choice (tuning).
+constexpr int kCUs = 256;
+inline int pick_bn(int64_t T, int64_t n_out) {
+  static const int pinned = [] {
+    const char* e = getenv("TE_LINEAR_BN");
+    return e ? atoi(e) : 0;
+  }();
+  if (pinned == 64 || pinned == 128) return pinned;
+  const int64_t nbm = te_ceil_div(T, BM);
+  auto eff = [&](int bn) {
+    const double per_cu = (double)(nbm * te_ceil_div(n_out, bn)) / kCUs;
+    return per_cu / (double)te_ceil_div(nbm * te_ceil_div(n_out, bn), kCUs);
+  };
+  return (0.96 * eff(64) > eff(128)) ? 64 : 128;
+}
+
+template <bool LRP, bool SWAP, int BN>
+inline void launch_k1(const float* X, const float* W, const float* R, float* S1, float* S2, int64_t T, int64_t in_f,
+                      int64_t out_f, hipStream_t stream) {
+  const int nbm = (int)te_ceil_div(T, BM), nbn = (int)te_ceil_div(out_f, BN);
+  allow_lds(linear_k1_kernel<LRP, SWAP, BN>, k1_lds<BN>());
+  linear_k1_kernel<LRP, SWAP, BN><<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), k1_lds<BN>(), stream>>>(
+      X, W, R, S1, S2, T, in_f, out_f, nbn);
+}
+template <int MODE, bool SWAP, bool ACCUM, int BN>
+inline void launch_k2(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
+                      int64_t out_f, float scale, hipStream_t stream) {
+  const int nbm = (int)te_ceil_div(T, BM), nbn = (int)te_ceil_div(in_f, BN);
+  allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BN>, k2_lds<BN>());
+  linear_k2_kernel<MODE, SWAP, ACCUM, BN><<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), k2_lds<BN>(), stream>>>(
+      S, W, X, out, T, out_f, in_f, nbn, scale);
 }
 
 template <bool SWAP, bool ACCUM>
@@ -375,29 +427,24 @@ int run_half(const float* R, const float* X, const float* W, float* out, int64_t
     }
     return TE_OK;
   }
-  const int nbm = (int)te_ceil_div(T, BM);
-  const int nbn1 = (int)te_ceil_div(out_f, BN), nbn2 = (int)te_ceil_div(in_f, BN);
-  dim3 blk(kThreads), g1((unsigned)(nbm * nbn1)), g2((unsigned)(nbm * nbn2));
+  const bool n1 = pick_bn(T, out_f) == 64, n2 = pick_bn(T, in_f) == 64;
   if (lrp) {
-    allow_lds(linear_k1_kernel<true, SWAP>, kK1Lds);
-    linear_k1_kernel<true, SWAP><<<g1, blk, kK1Lds, stream>>>(X, W, R, S1, S2, T, in_f, out_f, nbn1);
-    if constexpr (ACCUM) {
-      // out - beta*(C1 + C2) needs C1 + C2 first: form it in two accumulate steps on -scale
-      allow_lds(linear_k2_kernel<1, SWAP, true>, kK2Lds);
-      allow_lds(linear_k2_kernel<2, SWAP, true>, kK2Lds);
-      linear_k2_kernel<1, SWAP, true><<<g2, blk, kK2Lds, stream>>>(S1, W, X, out, T, out_f, in_f, nbn2, scale);
-      linear_k2_kernel<2, SWAP, true><<<g2, blk, kK2Lds, stream>>>(S2, W, X, out, T, out_f, in_f, nbn2, scale);
+    // the lrp variant's K1 holds two accumulator sets (128 registers at BN = 128); out - beta*(C1 + C2) is formed
+    // in two accumulate steps
+    if (n1) launch_k1<true, SWAP, 64>(X, W, R, S1, S2, T, in_f, out_f, stream);
+    else launch_k1<true, SWAP, 128>(X, W, R, S1, S2, T, in_f, out_f, stream);
+    if (n2) {
+      launch_k2<1, SWAP, ACCUM, 64>(S1, W, X, out, T, in_f, out_f, scale, stream);
+      launch_k2<2, SWAP, ACCUM, 64>(S2, W, X, out, T, in_f, out_f, scale, stream);
     } else {
-      allow_lds(linear_k2_kernel<1, SWAP, false>, kK2Lds);
-      allow_lds(linear_k2_kernel<2, SWAP, false>, kK2Lds);
-      linear_k2_kernel<1, SWAP, false><<<g2, blk, kK2Lds, stream>>>(S1, W, X, out, T, out_f, in_f, nbn2, scale);
-      linear_k2_kernel<2, SWAP, false><<<g2, blk, kK2Lds, stream>>>(S2, W, X, out, T, out_f, in_f, nbn2, scale);
+      launch_k2<1, SWAP, ACCUM, 128>(S1, W, X, out, T, in_f, out_f, scale, stream);
+      launch_k2<2, SWAP, ACCUM, 128>(S2, W, X, out, T, in_f, out_f, scale, stream);
     }
   } else {
-    allow_lds(linear_k1_kernel<false, SWAP>, kK1Lds);
-    allow_lds(linear_k2_kernel<0, SWAP, ACCUM>, kK2Lds);
-    linear_k1_kernel<false, SWAP><<<g1, blk, kK1Lds, stream>>>(X, W, R, S1, S1, T, in_f, out_f, nbn1);
-    linear_k2_kernel<0, SWAP, ACCUM><<<g2, blk, kK2Lds, stream>>>(S1, W, X, out, T, out_f, in_f, nbn2, scale);
+    if (n1) launch_k1<false, SWAP, 64>(X, W, R, S1, S1, T, in_f, out_f, stream);
+    else launch_k1<false, SWAP, 128>(X, W, R, S1, S1, T, in_f, out_f, stream);
+    if (n2) launch_k2<0, SWAP, ACCUM, 64>(S1, W, X, out, T, in_f, out_f, scale, stream);
+    else launch_k2<0, SWAP, ACCUM, 128>(S1, W, X, out, T, in_f, out_f, scale, stream);
   }
   return TE_OK;
 }
@@ -413,10 +460,8 @@ extern "C" int te_linear_zpass_f32(const float* R, const float* X, const float* 
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(R) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(S))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  const int nbm = (int)te_ceil_div(T, BM), nbn = (int)te_ceil_div(out_f, BN);
-  allow_lds(linear_k1_kernel<false, false>, kK1Lds);
-  linear_k1_kernel<false, false><<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), kK1Lds, stream>>>(X, W, R, S, S, T,
-                                                                                                 in_f, out_f, nbn);
+  if (pick_bn(T, out_f) == 64) launch_k1<false, false, 64>(X, W, R, S, S, T, in_f, out_f, stream);
+  else launch_k1<false, false, 128>(X, W, R, S, S, T, in_f, out_f, stream);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
@@ -427,11 +472,8 @@ extern "C" int te_linear_cpass_f32(const float* S, const float* X, const float* 
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(S) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(out))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  const int nbm = (int)te_ceil_div(T, BM), nbn = (int)te_ceil_div(in_f, BN);
-  allow_lds(linear_k2_kernel<0, false, false>, kK2Lds);
-  linear_k2_kernel<0, false, false><<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), kK2Lds, stream>>>(S, W, X, out, T,
-                                                                                                    out_f, in_f, nbn,
-                                                                                                    1.0f);
+  if (pick_bn(T, in_f) == 64) launch_k2<0, false, false, 64>(S, W, X, out, T, in_f, out_f, 1.0f, stream);
+  else launch_k2<0, false, false, 128>(S, W, X, out, T, in_f, out_f, 1.0f, stream);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }

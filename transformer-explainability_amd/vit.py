@@ -99,7 +99,10 @@ def make_vit_module(L):
 
         def relprop(self, cam, **kwargs):
             """ViT_LRP.py:154-177."""
-            cam = self.proj.relprop(cam, **kwargs)
+            return self.relprop_after_proj(self.proj.relprop(cam, **kwargs), **kwargs)
+
+        def relprop_after_proj(self, cam, **kwargs):
+            """ViT_LRP.py:157-177: everything below proj.relprop (the two attention rules and qkv.relprop)."""
             B, N, C = cam.shape
             H = self.num_heads
             D = C // H
@@ -141,6 +144,29 @@ def make_vit_module(L):
             cam1, cam2 = self.add1.relprop(cam, **kwargs)
             cam2 = self.attn.relprop(cam2, **kwargs)
             return self.clone1.relprop((cam1, cam2), **kwargs)
+
+        def relprop_cls_only(self, cam_cls, **kwargs):
+            """Block.relprop for relevance that lives on token 0 only (cam_cls [B,1,C]) -- the state right after
+            pool.relprop (ViT_LRP.py:329), i.e. the LAST block.  Every rule from add2 down to proj maps a zero
+            relevance row to an exact zero row (S = safe_divide(0, Z) = 0), and Add's per-sample sums gain only
+            zeros from those rows, so the six rules are evaluated on the [B,1,C] slice of their cached inputs and
+            the result is scattered into a zero [B,N,C] tensor before the attention rules, which spread relevance
+            to all tokens.  Bitwise equal to the dense evaluation at 1/N of its Linear work."""
+            alpha = kwargs.get("alpha", 1)
+            var = self.add2.variant
+            cls = lambda t: t[:, :1]                                             # noqa: E731
+            c1, c2 = ops.add_relprop(cam_cls, cls(self.add2.X[0]), cls(self.add2.X[1]), variant=var)
+            c2 = ops.linear_relprop(c2, cls(self.mlp.fc2.X), self.mlp.fc2.weight.detach(), alpha=alpha, variant=var)
+            c2 = ops.linear_relprop(c2, cls(self.mlp.fc1.X), self.mlp.fc1.weight.detach(), alpha=alpha, variant=var)
+            cam = ops.clone_relprop((c1, c2), cls(self.clone2.X))
+            c1, c2 = ops.add_relprop(cam, cls(self.add1.X[0]), cls(self.add1.X[1]), variant=var)
+            c2 = ops.linear_relprop(c2, cls(self.attn.proj.X), self.attn.proj.weight.detach(), alpha=alpha, variant=var)
+            B, N, C = self.clone1.X.shape
+            dense = torch.zeros((2, B, N, C), dtype=c2.dtype, device=c2.device)
+            dense[0, :, 0] = c1[:, 0]
+            dense[1, :, 0] = c2[:, 0]
+            cam2 = self.attn.relprop_after_proj(dense[1], **kwargs)
+            return self.clone1.relprop((dense[0], cam2), **kwargs)
 
     class PatchEmbed(nn.Module):
         def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
@@ -188,6 +214,7 @@ def make_vit_module(L):
             self.pool = L.IndexSelect()
             self.add = L.Add()
             self.inp_grad = None
+            self.exploit_cls_sparsity = True     # exact; set False to evaluate the last block densely
 
         def save_inp_grad(self, grad): self.inp_grad = grad
         def get_inp_grad(self): return self.inp_grad
@@ -224,8 +251,16 @@ def make_vit_module(L):
             if method is None:
                 method = self.default_method
             cam = self.head.relprop(cam, **kwargs)
-            cam = self.pool.relprop(cam.unsqueeze(1), **kwargs)
-            for blk in reversed(self.blocks):
+            if self.exploit_cls_sparsity and isinstance(self.head, nn.Linear):
+                # pool.relprop puts relevance on the class token only: keep it as a [B,1,C] row through the last
+                # block's dense rules instead of a [B,N,C] tensor that is zero everywhere else
+                cam = ops.index_select_relprop(cam.unsqueeze(1), self.pool.X[:, :1], 0)
+                cam = self.blocks[-1].relprop_cls_only(cam, **kwargs)
+                rest = list(self.blocks)[:-1]
+            else:
+                cam = self.pool.relprop(cam.unsqueeze(1), **kwargs)
+                rest = list(self.blocks)
+            for blk in reversed(rest):
                 cam = blk.relprop(cam, **kwargs)
 
             if method == "full":
