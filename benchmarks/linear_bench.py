@@ -2,7 +2,7 @@
 """Measurement infrastructure (not product code): per-shape rate of the two Linear.relprop kernels on one MI355X,
 next to the register-only fp32-MFMA rate the same chip sustains (benchmarks/mfma_peak.hip).
 
-    python benchmarks/linear_bench.py [--batch 64] [--bn 0|64|128]   (run on the GPU box)
+    [TE_LINEAR_TILE=128x128|128x64|64x64] python benchmarks/linear_bench.py [--batch 64] [--clock] [--lib ...]   (GPU box)
 """
 import argparse
 import ctypes
@@ -20,13 +20,20 @@ def main():
     ap.add_argument("--tokens", type=int, default=197)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--skip-peak", action="store_true")
+    ap.add_argument("--clock", action="store_true", help="sample the shader clock while each kernel runs")
+    ap.add_argument("--lib", default=None, help="alternative build of the C ABI (benchmarks/libte_ablate*.so)")
     args = ap.parse_args()
     import torch
     from transformer_explainability_amd import _lib
     lib = _lib.load()
     _lib.require_device()
+    if args.lib:
+        lib = ctypes.CDLL(os.path.abspath(args.lib))
+        for n in ("te_linear_zpass_f32", "te_linear_cpass_f32"):
+            getattr(lib, n).restype = ctypes.c_int
+            getattr(lib, n).argtypes = _lib.SIGNATURES[n][1]
     d = torch.device("cuda:0")
-    res = {"env_TE_LINEAR_BN": os.environ.get("TE_LINEAR_BN", "auto")}
+    res = {"env_TE_LINEAR_TILE": os.environ.get("TE_LINEAR_TILE", "auto"), "lib": args.lib or "product"}
 
     if not args.skip_peak:
         pk = ctypes.CDLL(os.path.join(ROOT, "benchmarks", "libmfma_peak.so"))
@@ -41,6 +48,26 @@ def main():
             res[f"mfma_peak_nacc{nacc}_blocks{bpc}"] = {"tflops": tf, "ms": ms.value}
             print(f"register-only mfma_f32_32x32x2: {nacc} accumulators, {bpc} block(s)/CU: {tf:7.1f} TF ({ms.value:.2f} ms)",
                   flush=True)
+
+    pk = ctypes.CDLL(os.path.join(ROOT, "benchmarks", "libmfma_peak.so"))
+    pk.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    pk.clock_probe_launch.restype = None
+    side = torch.cuda.Stream()
+    probe_out = torch.zeros(2, dtype=torch.int64, device=d)
+
+    def shader_mhz(work, spin_us=1500):
+        """run `work()` (enqueues ~3 ms of kernels on the current stream) with the clock probe on a side stream"""
+        torch.cuda.synchronize()
+        work()                                       # get going first
+        pk.clock_probe_launch(probe_out.data_ptr(), spin_us, side.cuda_stream)
+        work()
+        torch.cuda.synchronize()
+        c, r = [int(v) for v in probe_out.cpu()]
+        return c / max(r, 1) * 100.0
+
+    if args.clock:
+        res["shader_mhz_idle"] = shader_mhz(lambda: None)
+        print(f"shader clock, idle chip: {res['shader_mhz_idle']:.0f} MHz", flush=True)
 
     T = args.batch * args.tokens
     shapes = [("qkv", 768, 2304), ("proj", 768, 768), ("fc1", 768, 3072), ("fc2", 3072, 768)]
@@ -67,6 +94,13 @@ def main():
             us = e0.elapsed_time(e1) / args.reps * 1e3
             tf = flops / (us * 1e-6) / 1e12
             res[f"{name}.{kname}"] = {"us": us, "tflops": tf}
+            if args.clock:
+                n = max(2, int(2500 / us))
+                mhz = shader_mhz(lambda: [fn(*ptrs, T, in_f, out_f, st) for _ in range(n)])
+                res[f"{name}.{kname}"]["shader_mhz"] = mhz
+                res[f"{name}.{kname}"]["frac_of_clock_peak"] = tf / (157.3 * mhz / 2400.0)
+                print(f"      shader clock under this kernel: {mhz:.0f} MHz -> {tf / (157.3 * mhz / 2400.0) * 100:.1f} % of "
+                      f"the MFMA rate at that clock", flush=True)
             tot_f += flops
             tot_t += us * 1e-6
             print(f"{name:5s} {kname}  T={T} in={in_f} out={out_f}: {us:8.1f} us  {tf:6.1f} TF", flush=True)

@@ -60,3 +60,20 @@ extern "C" double mfma_peak_tflops(int nacc, int blocks_per_cu, int iters, float
   hipEventDestroy(e1);
   return flops / (ms * 1e-3) / 1e12;
 }
+
+// ---- shader-clock probe: one small block that samples the shader-cycle counter (s_memtime, DVFS-dependent) against
+// the constant 100 MHz real-time counter (s_memrealtime) while another stream runs the kernel under test.
+__global__ void clock_probe_kernel(unsigned long long* out, long long spin_ref_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long c0 = clock64(), r0 = wall_clock64();
+  unsigned long long r1 = r0;
+  while ((long long)(r1 - r0) < spin_ref_ticks) r1 = wall_clock64();
+  const unsigned long long c1 = clock64();
+  out[0] = c1 - c0;
+  out[1] = r1 - r0;
+}
+
+// launches the probe on `stream`; out = 2 x uint64 device words {shader cycles, 100 MHz ticks}
+extern "C" void clock_probe_launch(unsigned long long* out, long long spin_us, void* stream) {
+  clock_probe_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out, spin_us * 100);
+}

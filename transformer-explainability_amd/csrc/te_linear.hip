@@ -6,38 +6,54 @@
 //   K2 ("C-pass",  NN GEMM, K = out_f): P+[t,i] = sum_j S[t,j] W+[j,i] ; P-[t,i] = sum_j S[t,j] W-[j,i]
 //                                       out = X+ . P+ + X- . P-                      (epilogue)
 //
-// The positive / negative parts are formed in registers right before the MFMA (v_max/v_min on the
-// fragment that was just read from LDS), so X, W and S are each staged through LDS exactly once and no
-// clamped copy of W or X ever exists in HBM.  v_mfma_f32_32x32x2_f32 is an exact-f32 k-ordered fma
-// chain (MI355X guide), i.e. numerically a plain fp32 GEMM.
+// The positive / negative parts are formed in registers right before the MFMA (one VALU op on the fragment that
+// was just read from LDS), so X, W and S are each staged through LDS exactly once and no clamped copy of W or X
+// ever exists in HBM.  v_mfma_f32_32x32x2_f32 is an exact-f32 k-ordered fma chain (MI355X guide), i.e.
+// numerically a plain fp32 GEMM.
 //
-// Tiling: 256 threads = 4 waves as 2(M) x 2(N); block tile 128 x 128 x 32; each wave owns 64 x 64 =
-// 2 x 2 MFMA 32x32 accumulators (K1: 64 acc VGPRs; K2: 128, P+ and P- share the A fragments).
-// A-type tiles (K-contiguous rows: X, S, W in K1) sit in LDS as [128][36] floats -- the 4-float pad
-// makes the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots -- and each lane pulls FOUR
-// consecutive k of its row per ds_read_b128: lanes 0-31 supply k = kg*8+j, lanes 32-63 k = kg*8+4+j
-// to the j-th of four consecutive MFMAs (any k pairing is legal as long as A and B agree).
-// The K2 B tile (W rows = k, contiguous along n) is [32][128] and read with conflict-free ds_read_b32.
-// LDS is double-buffered (one __syncthreads per K step, global loads for step k+1 in flight during
-// the MFMAs of step k); 2 blocks/CU co-reside so one block's barrier hides under the other's MFMAs.
-// blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous run of tiles (n fastest), so
-// blocks that share an X/S row panel share an L2.
+// Tiling: 256 threads = 4 waves as 2(M) x 2(N); block tile BM x BN x 32 with (BM, BN) one of 128x128, 128x64,
+// 64x64, chosen per launch (pick_tile); each wave owns (BM/2) x (BN/2) = MI x NI accumulators of 32x32.
+// K-contiguous tiles (X, S, and W in K1) sit in LDS as [rows][32] floats with an XOR swizzle of the 16-B chunks
+// (swz()): conflict-free ds_read_b128 / ds_write_b128 without padding (measured: SQ_LDS_BANK_CONFLICT = 0).  Each
+// lane pulls FOUR consecutive k of its row per ds_read_b128: lanes 0-31 supply k = kg*8+j, lanes 32-63 k = kg*8+4+j
+// to the j-th of four consecutive MFMAs (any k pairing is legal as long as A and B agree).  The K2 B tile (W rows =
+// k, contiguous along n) is [32][BN], read with conflict-free ds_read_b32.  LDS is double-buffered (one
+// __syncthreads per K step, global loads for step k+1 in flight during the MFMAs of step k); 2 (64 KB), 3 (48 KB)
+// or 5 (32 KB) blocks co-reside per CU so one block's barrier and epilogue hide under the others' MFMAs.
+// blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous run of tiles (n fastest), so blocks that
+// share an X/S row panel share an L2.
 //
-// Odd shapes (in_f or out_f not a multiple of 4, or forced by TE_IMPL_SIMPLE) use plain one-thread-
-// per-output kernels; they double as the on-device cross-check for the tiled path.
+// fp32 MFMA runs at 1/16 of the bf16 rate, so LDS and L2 bandwidth are idle at every tile size (8 B/clk/CU of LDS
+// reads against 256); what the tile choice trades is granularity (tiles per CU in the last round) against the
+// number of co-resident waves that cover barriers and epilogues.  DESIGN.md section 3 has the ablation study.
+//
+// Odd shapes (in_f or out_f not a multiple of 4, or forced by TE_IMPL_SIMPLE) use plain one-thread-per-output
+// kernels; they double as the on-device cross-check for the tiled path.
 #include <stdlib.h>
+#include <string.h>
 
 #include "te_common.h"
 
+// Measurement builds only (benchmarks/build_ablations.sh): TE_ABLATION = 1 main loop without global loads / LDS
+// stores / barriers (the first tile is reused), 2 = 1 + operands fed to the MFMAs without the +/- split,
+// 3 = full loop, epilogue without safe_divide.  The product library is always built with 0.
+#ifndef TE_ABLATION
+#define TE_ABLATION 0
+#endif
+
 namespace {
 
-constexpr int BM = 128, BK = 32;
-constexpr int LDT = BK + 4;       // padded leading dim of K-contiguous tiles (floats)
+constexpr int BK = 32;
+constexpr int LDT = BK;           // K-contiguous tiles are [rows][32] floats = 128-B rows, XOR-swizzled (swz())
 constexpr int kThreads = 256;
-// The block tile is BM x BN with BN = 128 (each wave 64 x 64 = 2 x 2 MFMA blocks) or BN = 64 (each wave 64 x 32 =
-// 2 x 1).  fp32 MFMA is 16x slower than bf16 MFMA, so even the narrow tile leaves LDS / L2 bandwidth idle; what it
-// buys is granularity: a 12,608 x 768 output is 594 wide tiles = 2.32 per CU (a third round that is 1/3 full),
-// but 1188 narrow tiles = 4.64 per CU.  pick_bn() chooses per launch.
+constexpr int kCUs = 256;
+constexpr size_t kLdsPerCU = 160 * 1024;
+
+// 16-B chunk c (0..7) of row r lives at chunk c ^ ((r >> 1) & 7).  With 128-B rows two consecutive rows span
+// the 256-B bank row, so a ds_read_b128 lane group (16 lanes = 16 different rows, 8 even + 8 odd, same logical
+// chunk) lands on 16 distinct 16-B slots iff the 8 rows of one parity get 8 distinct XOR masks -- (r >> 1) & 7
+// does that for every lane group of the instruction ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32).
+__device__ __forceinline__ int swz(int row, int chunk) { return row * LDT + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
   // bijective remap: XCD x (= bid % 8 by dispatch order) gets a contiguous run of logical tiles
@@ -53,7 +69,7 @@ __device__ __forceinline__ void load_rows_tile(const float* __restrict__ M, int6
                                                int64_t row0, int64_t k0, f32x4 (&reg)[ROWS / 32]) {
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
-    const int idx = threadIdx.x + i * kThreads;  // 0..1023
+    const int idx = threadIdx.x + i * kThreads;
     const int row = idx >> 3, c4 = idx & 7;
     const int64_t gr = row0 + row, gk = k0 + c4 * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -67,7 +83,7 @@ __device__ __forceinline__ void store_rows_tile(float* __restrict__ lds, const f
   for (int i = 0; i < ROWS / 32; ++i) {
     const int idx = threadIdx.x + i * kThreads;
     const int row = idx >> 3, c4 = idx & 7;
-    *reinterpret_cast<f32x4*>(lds + row * LDT + c4 * 4) = reg[i];
+    *reinterpret_cast<f32x4*>(lds + swz(row, c4)) = reg[i];
   }
 }
 // Stage a [32 k][BN n] tile of a row-major K x N matrix (ld = Nn).
@@ -94,35 +110,53 @@ __device__ __forceinline__ void store_kn_tile(float* __restrict__ lds, const f32
   }
 }
 
+// x+ = max(x, 0), x- = min(x, 0).  Builtins on purpose: hipcc pads the VALU-write -> MFMA-operand hazard for
+// instructions it knows, not for inline asm (an asm v_max_f32 here fed stale operands to the MFMAs).
+__device__ __forceinline__ float te_pos(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+__device__ __forceinline__ float te_neg(float x) { return __builtin_amdgcn_fmed3f(x, -__builtin_inff(), 0.0f); }
+
 #define TE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+struct TileCoord {
+  int64_t row0, col0;
+};
+template <int BM, int BN>
+__device__ __forceinline__ TileCoord tile_coord(int v, int ntiles, int nbn) {
+  const int tile = xcd_swizzle(v, ntiles);
+  return {(int64_t)(tile / nbn) * BM, (int64_t)(tile % nbn) * BN};
+}
+
+// Both kernels walk the tiles v = blockIdx.x, + gridDim.x, ...  With the default launch (grid = number of tiles)
+// that is one tile per block; with a persistent grid (TE_LINEAR_PERSIST=1: blocks-per-CU x 256, a multiple of 8 so
+// a block keeps its XCD) the K-steps of a block's tiles form one software pipeline in which the first operands of
+// the next tile are fetched under the last K-step of the current one.  Measured neutral on MI355X, so
+// the simpler launch is the default.
 
 // ------------------------------------------------------------------------------------------------
 // K1: S = sd(R, X+ W+^T + X- W-^T)        SWAP exchanges W+ / W- (inhibitor term, beta != 0)
 //     LRP: S1 = sd(R, X+ W+^T), S2 = sd(R, X- W-^T) kept apart (layers_lrp.py:199-200)
 // ------------------------------------------------------------------------------------------------
-template <bool LRP, bool SWAP, int BN>
+template <bool LRP, bool SWAP, int BM, int BN>
 __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ R,
-    float* __restrict__ S1, float* __restrict__ S2, int64_t T, int64_t K, int64_t Nn, int nbn) {
+    float* __restrict__ S1, float* __restrict__ S2, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NI = BN / 64;                 // 32-wide MFMA column blocks per wave
-  constexpr int WN = BN / 2;                  // columns per wave
+  constexpr int MI = BM / 64, NI = BN / 64;   // 32x32 MFMA blocks per wave
+  constexpr int WM = BM / 2, WN = BN / 2;     // rows / columns per wave
   constexpr int A_SZ = BM * LDT;
   constexpr int STAGE = (BM + BN) * LDT;      // floats per pipeline stage: [A tile | B tile]
 
-  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int64_t row0 = (int64_t)(tile / nbn) * BM;
-  const int64_t col0 = (int64_t)(tile % nbn) * BN;
+  const int G = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, kh = lane >> 5;
 
   constexpr int NACC = LRP ? 2 : 1;
-  f32x16 acc[NACC][2][NI];
+  f32x16 acc[NACC][MI][NI];
 #pragma unroll
   for (int s = 0; s < NACC; ++s)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -130,79 +164,120 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 
   f32x4 ra[BM / 32], rb[BN / 32];
   const int nk = (int)((K + BK - 1) / BK);
-  load_rows_tile<BM>(X, T, K, row0, 0, ra);
-  load_rows_tile<BN>(W, Nn, K, col0, 0, rb);
+  int v = blockIdx.x;
+  TileCoord tc = tile_coord<BM, BN>(v, ntiles, nbn);
+  load_rows_tile<BM>(X, T, K, tc.row0, 0, ra);
+  load_rows_tile<BN>(W, Nn, K, tc.col0, 0, rb);
   store_rows_tile<BM>(smem, ra);
   store_rows_tile<BN>(smem + A_SZ, rb);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      load_rows_tile<BM>(X, T, K, row0, (int64_t)(kt + 1) * BK, ra);
-      load_rows_tile<BN>(W, Nn, K, col0, (int64_t)(kt + 1) * BK, rb);
-    }
-    const float* a_base = smem + cur * STAGE + (wm * 64 + lr) * LDT + kh * 4;
-    const float* b_base = smem + cur * STAGE + A_SZ + (wn * WN + lr) * LDT + kh * 4;
+  // one K-step of MFMAs on the LDS stage `cur`
+  auto mma = [&](int cur) __attribute__((always_inline)) {
+    const float* a_tile = smem + cur * STAGE;
+    const float* b_tile = smem + cur * STAGE + A_SZ;
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
-      f32x4 a[2], b[NI];
+      f32x4 a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a_base + mi * 32 * LDT + kg * 8);
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *reinterpret_cast<const f32x4*>(a_tile + swz(wm * WM + mi * 32 + lr, kg * 2 + kh));
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(b_base + ni * 32 * LDT + kg * 8);
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = *reinterpret_cast<const f32x4*>(b_tile + swz(wn * WN + ni * 32 + lr, kg * 2 + kh));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float ap[2], an[2], bp[NI], bn[NI];
+        float ap[MI], an[MI], bp[NI], bn[NI];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          ap[mi] = fmaxf(a[mi][j], 0.0f);
-          an[mi] = fminf(a[mi][j], 0.0f);
+        for (int mi = 0; mi < MI; ++mi) {
+          ap[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_pos(a[mi][j]);
+          an[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_neg(a[mi][j]);
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          const float p = fmaxf(b[ni][j], 0.0f), n = fminf(b[ni][j], 0.0f);
+          const float p = (TE_ABLATION == 2) ? b[ni][j] : te_pos(b[ni][j]);
+          const float n = (TE_ABLATION == 2) ? b[ni][j] : te_neg(b[ni][j]);
           bp[ni] = SWAP ? n : p;   // partner of X+
           bn[ni] = SWAP ? p : n;   // partner of X-
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(ap[mi], bp[ni], acc[0][mi][ni]);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[NACC - 1][mi][ni] = TE_MFMA(an[mi], bn[ni], acc[NACC - 1][mi][ni]);
       }
     }
-    if (kt + 1 < nk) {
+  };
+  constexpr bool kStaged = (TE_ABLATION != 1 && TE_ABLATION != 2);
+
+  int cur = 0;
+  for (; v < ntiles; v += G) {
+    const bool has_next = (v + G) < ntiles;
+    // ---- K-steps 0 .. nk-2: operands of step kt+1 in flight under the MFMAs of step kt
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      if (kStaged) {
+        load_rows_tile<BM>(X, T, K, tc.row0, (int64_t)(kt + 1) * BK, ra);
+        load_rows_tile<BN>(W, Nn, K, tc.col0, (int64_t)(kt + 1) * BK, rb);
+      }
+      mma(kStaged ? cur : 0);
+      if (!kStaged) {
+        asm volatile("" ::: "memory");   // keep the LDS fragment reads inside the loop
+        continue;
+      }
       store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
       store_rows_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
+      __syncthreads();
+      cur ^= 1;
     }
-    __syncthreads();
-  }
-
-  // epilogue: C/D layout of 32x32 MFMA -- col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int64_t gc = col0 + wn * WN + ni * 32 + lr;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t gr = row0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (gr < T && gc < Nn) {
-          const float r = R[gr * Nn + gc];
-          if constexpr (LRP) {
-            S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
-            S2[gr * Nn + gc] = te_sd(r, acc[1][mi][ni][e]);
-          } else {
-            S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
-          }
-        }
+    // ---- last K-step (persistent grids: the FIRST operands of this block's next tile in flight under it)
+    TileCoord tn = tc;
+    if (has_next) {
+      tn = tile_coord<BM, BN>(v + G, ntiles, nbn);
+      if (kStaged) {
+        load_rows_tile<BM>(X, T, K, tn.row0, 0, ra);
+        load_rows_tile<BN>(W, Nn, K, tn.col0, 0, rb);
       }
     }
+    mma(kStaged ? cur : 0);
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    // (An "interior tile" fast path with scalar-base addressing was tried: it doubled the live address registers
+    // and cost a co-resident block per CU -- not kept.)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          if (gr < T && gc < Nn) {
+            const float r = R[gr * Nn + gc];
+            if constexpr (LRP) {
+              S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
+              S2[gr * Nn + gc] = te_sd(r, acc[1][mi][ni][e]);
+            } else {
+              S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < NACC; ++s) acc[s][mi][ni][e] = 0.0f;
+        }
+      }
+    if (kStaged) {
+      if (has_next) {
+        store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
+        store_rows_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    tc = tn;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -211,28 +286,26 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 //     MODE 2: out += scale * X- . (S W(-))   (lrp second half, S = S2)
 //     SWAP exchanges W+ / W-.  ACCUM: out = out - scale * (...)   (the beta * inhibitor term)
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool SWAP, bool ACCUM, int BN>
+template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
 __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
     const float* __restrict__ S, const float* __restrict__ W, const float* __restrict__ X,
-    float* __restrict__ out, int64_t T, int64_t K, int64_t Nn, int nbn, float scale) {
+    float* __restrict__ out, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NI = BN / 64, WN = BN / 2;
+  constexpr int MI = BM / 64, NI = BN / 64, WM = BM / 2, WN = BN / 2;
   constexpr int A_SZ = BM * LDT, B_SZ = BK * BN;
   constexpr int STAGE = A_SZ + B_SZ;   // floats per pipeline stage: [A tile | B tile]
 
-  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int64_t row0 = (int64_t)(tile / nbn) * BM;
-  const int64_t col0 = (int64_t)(tile % nbn) * BN;
+  const int G = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, kh = lane >> 5;
 
   constexpr int NACC = (MODE == 0) ? 2 : 1;
-  f32x16 acc[NACC][2][NI];
+  f32x16 acc[NACC][MI][NI];
 #pragma unroll
   for (int s = 0; s < NACC; ++s)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -240,79 +313,117 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
 
   f32x4 ra[BM / 32], rb[BN / 32];
   const int nk = (int)((K + BK - 1) / BK);
-  load_rows_tile<BM>(S, T, K, row0, 0, ra);
-  load_kn_tile<BN>(W, K, Nn, 0, col0, rb);
+  int v = blockIdx.x;
+  TileCoord tc = tile_coord<BM, BN>(v, ntiles, nbn);
+  load_rows_tile<BM>(S, T, K, tc.row0, 0, ra);
+  load_kn_tile<BN>(W, K, Nn, 0, tc.col0, rb);
   store_rows_tile<BM>(smem, ra);
   store_kn_tile<BN>(smem + A_SZ, rb);
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      load_rows_tile<BM>(S, T, K, row0, (int64_t)(kt + 1) * BK, ra);
-      load_kn_tile<BN>(W, K, Nn, (int64_t)(kt + 1) * BK, col0, rb);
-    }
-    const float* a_base = smem + cur * STAGE + (wm * 64 + lr) * LDT + kh * 4;
+  auto mma = [&](int cur) __attribute__((always_inline)) {
+    const float* a_tile = smem + cur * STAGE;
     const float* b_base = smem + cur * STAGE + A_SZ + (kh * 4) * BN + wn * WN + lr;
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
-      f32x4 a[2];
+      f32x4 a[MI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(a_base + mi * 32 * LDT + kg * 8);
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *reinterpret_cast<const f32x4*>(a_tile + swz(wm * WM + mi * 32 + lr, kg * 2 + kh));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float bp[NI], bn[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const float w = b_base[(kg * 8 + j) * BN + ni * 32];
-          const float p = fmaxf(w, 0.0f), n = fminf(w, 0.0f);
+          const float p = (TE_ABLATION == 2) ? w : te_pos(w), n = (TE_ABLATION == 2) ? w : te_neg(w);
           bp[ni] = SWAP ? n : p;
           bn[ni] = SWAP ? p : n;
         }
         if constexpr (MODE == 0 || MODE == 1) {
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(a[mi][j], bp[ni], acc[0][mi][ni]);
         }
         if constexpr (MODE == 0 || MODE == 2) {
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
               acc[NACC - 1][mi][ni] = TE_MFMA(a[mi][j], bn[ni], acc[NACC - 1][mi][ni]);
         }
       }
     }
-    if (kt + 1 < nk) {
+  };
+  constexpr bool kStaged = (TE_ABLATION != 1 && TE_ABLATION != 2);
+
+  int cur = 0;
+  for (; v < ntiles; v += G) {
+    const bool has_next = (v + G) < ntiles;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      if (kStaged) {
+        load_rows_tile<BM>(S, T, K, tc.row0, (int64_t)(kt + 1) * BK, ra);
+        load_kn_tile<BN>(W, K, Nn, (int64_t)(kt + 1) * BK, tc.col0, rb);
+      }
+      mma(kStaged ? cur : 0);
+      if (!kStaged) {
+        asm volatile("" ::: "memory");   // keep the LDS fragment reads inside the loop
+        continue;
+      }
       store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
       store_kn_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
+      __syncthreads();
+      cur ^= 1;
     }
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int64_t gc = col0 + wn * WN + ni * 32 + lr;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t gr = row0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (gr < T && gc < Nn) {
-          const float x = X[gr * Nn + gc];
-          const float xp = fmaxf(x, 0.0f), xn = fminf(x, 0.0f);
-          float v;
-          if constexpr (MODE == 0) v = xp * acc[0][mi][ni][e] + xn * acc[1][mi][ni][e];
-          else if constexpr (MODE == 1) v = xp * acc[0][mi][ni][e];
-          else v = xn * acc[0][mi][ni][e];
-          v = scale * v;
-          if constexpr (ACCUM) v = out[gr * Nn + gc] - v;          // alpha*act - beta*inh
-          else if constexpr (MODE == 2) v = out[gr * Nn + gc] + v;  // C1 + C2 of the lrp variant
-          out[gr * Nn + gc] = v;
-        }
+    TileCoord tn = tc;
+    if (has_next) {
+      tn = tile_coord<BM, BN>(v + G, ntiles, nbn);
+      if (kStaged) {
+        load_rows_tile<BM>(S, T, K, tn.row0, 0, ra);
+        load_kn_tile<BN>(W, K, Nn, 0, tn.col0, rb);
       }
     }
+    mma(kStaged ? cur : 0);
+
+    auto finish = [&](float x, float old, int mi, int ni, int e) __attribute__((always_inline)) -> float {
+      const float xp = fmaxf(x, 0.0f), xn = fminf(x, 0.0f);
+      float val;
+      if constexpr (MODE == 0) val = xp * acc[0][mi][ni][e] + xn * acc[1][mi][ni][e];
+      else if constexpr (MODE == 1) val = xp * acc[0][mi][ni][e];
+      else val = xn * acc[0][mi][ni][e];
+      val = scale * val;
+      if constexpr (ACCUM) val = old - val;          // alpha*act - beta*inh
+      else if constexpr (MODE == 2) val = old + val;  // C1 + C2 of the lrp variant
+      return val;
+    };
+    constexpr bool kReadsOut = ACCUM || MODE == 2;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          if (gr < T && gc < Nn) {
+            const float old = kReadsOut ? out[gr * Nn + gc] : 0.0f;
+            out[gr * Nn + gc] = finish(X[gr * Nn + gc], old, mi, ni, e);
+          }
+#pragma unroll
+          for (int s = 0; s < NACC; ++s) acc[s][mi][ni][e] = 0.0f;
+        }
+      }
+    if (kStaged) {
+      if (has_next) {
+        store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
+        store_kn_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    tc = tn;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,10 +473,13 @@ __global__ __launch_bounds__(kThreads) void linear_k2_simple(
   out[idx] = v;
 }
 
-template <int BN>
-constexpr size_t k1_lds() { return (size_t)2 * (BM + BN) * LDT * sizeof(float); }          // 73,728 / 55,296 B
-template <int BN>
-constexpr size_t k2_lds() { return (size_t)2 * (BM * LDT + BK * BN) * sizeof(float); }      // 69,632 / 53,248 B
+// ------------------------------------------------------------------------------------------------
+// host side: tile choice and launches
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+constexpr size_t k1_lds() { return (size_t)2 * (BM + BN) * LDT * sizeof(float); }          // 64 / 48 / 32 KB
+template <int BM, int BN>
+constexpr size_t k2_lds() { return (size_t)2 * (BM * LDT + BK * BN) * sizeof(float); }      // 64 / 48 / 32 KB
 
 template <typename Kern>
 inline void allow_lds(Kern kern, size_t bytes) {
@@ -376,41 +490,73 @@ inline void allow_lds(Kern kern, size_t bytes) {
                               (int)bytes);
 }
 
-// Tile-width choice per launch.  Work is issued in rounds of one tile per CU-slot; a launch whose tile count is
-// just above a multiple of the CU count wastes most of its last round.  Estimate the chip-level efficiency of
-// each width as (tiles / CUs) / ceil(tiles / CUs) -- times 0.96 for the narrow tile, whose B operand is re-staged
-// twice as often -- and take the better one.  TE_LINEAR_BN = 64 | 128 in the environment pins the choice (tuning).
-constexpr int kCUs = 256;
-inline int pick_bn(int64_t T, int64_t n_out) {
+enum Tile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2 };
+
+// Tile choice per launch.  A launch whose tile count is just above a multiple of the CU count wastes most of its
+// last round: 12,608 x 768 outputs are 594 tiles of 128x128 = 2.32 per CU (the third round a third full) but 1188
+// of 128x64 = 4.64 per CU.  Estimated chip efficiency of a tile = (tiles / CUs) / ceil(tiles / CUs) x a per-tile
+// factor; the best estimate wins.  TE_LINEAR_TILE = 128x128 | 128x64 | 64x64 pins the choice (tuning).
+inline Tile pick_tile(int64_t T, int64_t n_out) {
   static const int pinned = [] {
-    const char* e = getenv("TE_LINEAR_BN");
-    return e ? atoi(e) : 0;
+    const char* e = getenv("TE_LINEAR_TILE");
+    if (!e) return -1;
+    if (!strcmp(e, "128x128")) return (int)TILE_128x128;
+    if (!strcmp(e, "128x64")) return (int)TILE_128x64;
+    if (!strcmp(e, "64x64")) return (int)TILE_64x64;
+    return -1;
   }();
-  if (pinned == 64 || pinned == 128) return pinned;
-  const int64_t nbm = te_ceil_div(T, BM);
-  auto eff = [&](int bn) {
-    const double per_cu = (double)(nbm * te_ceil_div(n_out, bn)) / kCUs;
-    return per_cu / (double)te_ceil_div(nbm * te_ceil_div(n_out, bn), kCUs);
+  if (pinned >= 0) return (Tile)pinned;
+  auto eff = [&](int bm, int bn, double factor) {
+    const int64_t tiles = te_ceil_div(T, bm) * te_ceil_div(n_out, bn);
+    return factor * ((double)tiles / kCUs) / (double)te_ceil_div(tiles, kCUs);
   };
-  return (0.96 * eff(64) > eff(128)) ? 64 : 128;
+  const double e0 = eff(128, 128, 1.0), e1 = eff(128, 64, 0.98), e2 = eff(64, 64, 0.93);
+  if (e2 > e1 && e2 > e0) return TILE_64x64;
+  return (e1 > e0) ? TILE_128x64 : TILE_128x128;
 }
 
-template <bool LRP, bool SWAP, int BN>
+// grid: one block per tile, or (TE_LINEAR_PERSIST=1) as many co-resident blocks as LDS admits per CU x 256
+template <size_t LDS_BYTES>
+inline int grid_for(int ntiles) {
+  static const int persist = [] {
+    const char* e = getenv("TE_LINEAR_PERSIST");
+    return e ? atoi(e) : 0;
+  }();
+  if (!persist) return ntiles;
+  constexpr int fit = (int)(kLdsPerCU / LDS_BYTES);
+  constexpr int per_cu = fit > 5 ? 5 : fit;
+  return ntiles < kCUs * per_cu ? ntiles : kCUs * per_cu;
+}
+
+template <bool LRP, bool SWAP, int BM, int BN>
 inline void launch_k1(const float* X, const float* W, const float* R, float* S1, float* S2, int64_t T, int64_t in_f,
                       int64_t out_f, hipStream_t stream) {
-  const int nbm = (int)te_ceil_div(T, BM), nbn = (int)te_ceil_div(out_f, BN);
-  allow_lds(linear_k1_kernel<LRP, SWAP, BN>, k1_lds<BN>());
-  linear_k1_kernel<LRP, SWAP, BN><<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), k1_lds<BN>(), stream>>>(
-      X, W, R, S1, S2, T, in_f, out_f, nbn);
+  const int nbn = (int)te_ceil_div(out_f, BN);
+  const int ntiles = (int)te_ceil_div(T, BM) * nbn;
+  constexpr size_t lds = k1_lds<BM, BN>();
+  allow_lds(linear_k1_kernel<LRP, SWAP, BM, BN>, lds);
+  linear_k1_kernel<LRP, SWAP, BM, BN><<<dim3((unsigned)grid_for<lds>(ntiles)), dim3(kThreads), lds, stream>>>(
+      X, W, R, S1, S2, T, in_f, out_f, nbn, ntiles);
 }
-template <int MODE, bool SWAP, bool ACCUM, int BN>
+template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
 inline void launch_k2(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
                       int64_t out_f, float scale, hipStream_t stream) {
-  const int nbm = (int)te_ceil_div(T, BM), nbn = (int)te_ceil_div(in_f, BN);
-  allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BN>, k2_lds<BN>());
-  linear_k2_kernel<MODE, SWAP, ACCUM, BN><<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), k2_lds<BN>(), stream>>>(
-      S, W, X, out, T, out_f, in_f, nbn, scale);
+  const int nbn = (int)te_ceil_div(in_f, BN);
+  const int ntiles = (int)te_ceil_div(T, BM) * nbn;
+  constexpr size_t lds = k2_lds<BM, BN>();
+  allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN>, lds);
+  linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN><<<dim3((unsigned)grid_for<lds>(ntiles)), dim3(kThreads), lds, stream>>>(
+      S, W, X, out, T, out_f, in_f, nbn, ntiles, scale);
 }
+
+#define TE_DISPATCH_TILE(tile, CALL)                  \
+  do {                                                \
+    switch (tile) {                                   \
+      case TILE_128x128: { CALL(128, 128); } break;   \
+      case TILE_128x64: { CALL(128, 64); } break;     \
+      default: { CALL(64, 64); } break;               \
+    }                                                 \
+  } while (0)
 
 template <bool SWAP, bool ACCUM>
 int run_half(const float* R, const float* X, const float* W, float* out, int64_t T, int64_t in_f,
@@ -427,24 +573,24 @@ int run_half(const float* R, const float* X, const float* W, float* out, int64_t
     }
     return TE_OK;
   }
-  const bool n1 = pick_bn(T, out_f) == 64, n2 = pick_bn(T, in_f) == 64;
+  const Tile t1 = pick_tile(T, out_f), t2 = pick_tile(T, in_f);
   if (lrp) {
-    // the lrp variant's K1 holds two accumulator sets (128 registers at BN = 128); out - beta*(C1 + C2) is formed
-    // in two accumulate steps
-    if (n1) launch_k1<true, SWAP, 64>(X, W, R, S1, S2, T, in_f, out_f, stream);
-    else launch_k1<true, SWAP, 128>(X, W, R, S1, S2, T, in_f, out_f, stream);
-    if (n2) {
-      launch_k2<1, SWAP, ACCUM, 64>(S1, W, X, out, T, in_f, out_f, scale, stream);
-      launch_k2<2, SWAP, ACCUM, 64>(S2, W, X, out, T, in_f, out_f, scale, stream);
-    } else {
-      launch_k2<1, SWAP, ACCUM, 128>(S1, W, X, out, T, in_f, out_f, scale, stream);
-      launch_k2<2, SWAP, ACCUM, 128>(S2, W, X, out, T, in_f, out_f, scale, stream);
-    }
+    // the lrp variant's K1 holds two accumulator sets; out - beta*(C1 + C2) is formed in two accumulate steps
+#define TE_K1(BM_, BN_) launch_k1<true, SWAP, BM_, BN_>(X, W, R, S1, S2, T, in_f, out_f, stream)
+    TE_DISPATCH_TILE(t1, TE_K1);
+#undef TE_K1
+#define TE_K2(BM_, BN_)                                                                   \
+  launch_k2<1, SWAP, ACCUM, BM_, BN_>(S1, W, X, out, T, in_f, out_f, scale, stream);      \
+  launch_k2<2, SWAP, ACCUM, BM_, BN_>(S2, W, X, out, T, in_f, out_f, scale, stream)
+    TE_DISPATCH_TILE(t2, TE_K2);
+#undef TE_K2
   } else {
-    if (n1) launch_k1<false, SWAP, 64>(X, W, R, S1, S1, T, in_f, out_f, stream);
-    else launch_k1<false, SWAP, 128>(X, W, R, S1, S1, T, in_f, out_f, stream);
-    if (n2) launch_k2<0, SWAP, ACCUM, 64>(S1, W, X, out, T, in_f, out_f, scale, stream);
-    else launch_k2<0, SWAP, ACCUM, 128>(S1, W, X, out, T, in_f, out_f, scale, stream);
+#define TE_K1(BM_, BN_) launch_k1<false, SWAP, BM_, BN_>(X, W, R, S1, S1, T, in_f, out_f, stream)
+    TE_DISPATCH_TILE(t1, TE_K1);
+#undef TE_K1
+#define TE_K2(BM_, BN_) launch_k2<0, SWAP, ACCUM, BM_, BN_>(S1, W, X, out, T, in_f, out_f, scale, stream)
+    TE_DISPATCH_TILE(t2, TE_K2);
+#undef TE_K2
   }
   return TE_OK;
 }
@@ -460,8 +606,9 @@ extern "C" int te_linear_zpass_f32(const float* R, const float* X, const float* 
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(R) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(S))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  if (pick_bn(T, out_f) == 64) launch_k1<false, false, 64>(X, W, R, S, S, T, in_f, out_f, stream);
-  else launch_k1<false, false, 128>(X, W, R, S, S, T, in_f, out_f, stream);
+#define TE_K1(BM_, BN_) launch_k1<false, false, BM_, BN_>(X, W, R, S, S, T, in_f, out_f, stream)
+  TE_DISPATCH_TILE(pick_tile(T, out_f), TE_K1);
+#undef TE_K1
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
@@ -472,8 +619,9 @@ extern "C" int te_linear_cpass_f32(const float* S, const float* X, const float* 
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(S) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(out))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  if (pick_bn(T, in_f) == 64) launch_k2<0, false, false, 64>(S, W, X, out, T, in_f, out_f, 1.0f, stream);
-  else launch_k2<0, false, false, 128>(S, W, X, out, T, in_f, out_f, 1.0f, stream);
+#define TE_K2(BM_, BN_) launch_k2<0, false, false, BM_, BN_>(S, W, X, out, T, in_f, out_f, 1.0f, stream)
+  TE_DISPATCH_TILE(pick_tile(T, in_f), TE_K2);
+#undef TE_K2
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
