@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--cpu-baseline", choices=["auto", "port", "off"], default="auto")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="micro-batches in flight on separate HIP streams")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="consecutive steps (batches) in flight, each on its own HIP stream: the forward/backward of "
+                         "step k+1 overlaps the relprop of step k")
     args = ap.parse_args()
     faulthandler.enable()
     faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)   # a stuck run leaves a stack trace
@@ -188,8 +191,23 @@ def main():
     if not args.no_roofline:
         ops.KERNEL_TIMER = timer
 
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
+    counter = [0]
+
     def step():
-        return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
+        if lanes is None:
+            return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
+        # every tensor of a step is allocated, produced and consumed on that step's stream
+        lane = lanes[counter[0] % len(lanes)]
+        counter[0] += 1
+        lane.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(lane):
+            return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
+
+    def join():
+        if lanes is not None:
+            for lane in lanes:
+                torch.cuda.current_stream(dev).wait_stream(lane)
 
     for w in range(args.warmup):
         maps = step()
@@ -203,6 +221,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         maps = step()
+    join()
     gathered = parallel.gather_maps(maps, world * B)
     torch.cuda.synchronize()
     if world > 1:
@@ -228,16 +247,28 @@ def main():
             "config": {"workload": "ViT-B/16 224^2 batch 64 on 1xMI355X: stock fwd + attn-grad bwd + fp32 relprop/"
                                    "head-mean/rollout HIP kernels (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": 197, "blocks": 12,
-                       "start_layer": args.start_layer, "streams": args.streams, "parallelism": f"dp{world} (independent samples, one "
+                       "start_layer": args.start_layer, "streams": args.streams, "steps_in_flight": args.inflight, "parallelism": f"dp{world} (independent samples, one "
                                                                       f"all_gather of the maps)"},
         }
         roof = None
+        traffic = None
+        try:   # HBM-side bytes per C-pass launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
+               # MI355X guide's gfx950 correction); only valid for the B = 64 workload they were collected on
+            if B == 64:
+                with open(os.path.join(ROOT, "profiles", "r01_linear_traffic_pmc.json")) as f:
+                    tr = json.load(f)
+                cps = [v["traffic_bytes"] for k, v in tr.items() if k.endswith(".cpass")]
+                traffic = sum(cps) / len(cps)
+        except (OSError, ValueError, KeyError):
+            traffic = None
         cp = timer.summary("linear_cpass")
         zp = timer.summary("linear_zpass")
         if cp:
             roof = {"bound": "mfma", "kernel": "linear_k2_kernel<0,false,false> (Linear.relprop C-pass)",
                     "achieved": cp["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": cp["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "frac": cp["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_note": "bytes per launch, mean of the 4 C-pass shapes of a block; offline rocprofv3 --pmc "
+                                    "FETCH_SIZE / WRITE_SIZE passes (profiles/r01_linear_traffic_pmc.json)",
                     "launches_timed": cp["launches"], "avg_launch_us": cp["avg_us"],
                     "algorithmic_flops_per_launch_avg": cp["flops_per_launch_avg"],
                     "zpass": {"achieved": zp["tflops"], "avg_launch_us": zp["avg_us"]} if zp else None}

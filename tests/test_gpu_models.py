@@ -303,5 +303,103 @@ def test_bert_base_golden_and_oracle(golden_bert_base):
         ref = O.bert_relprop(oh, cache, num_heads=12, start_layer=sl)
         _assert_map(f"bert_base.oracle.map_sl{sl}", out, ref["map"], norm_tol=2e-4, rel_tol=3e-4)
         _assert_map(f"bert_base.golden.map_sl{sl}", out, g[f"map_sl{sl}"], **LOOSE)
+    # exact token-0 sparsity shortcut of the last layer (bert.BertLayer.relprop_cls_only) == dense evaluation
+    oh_d = _one_hot_of(model.classifier.Y.detach())
+    sparse_cam = model.relprop(oh_d, alpha=1)
+    sparse_cams = [lay.attention.self.get_attn_cam().clone() for lay in model.bert.encoder.layer]
+    model.bert.exploit_cls_sparsity = False
+    dense_cam = model.relprop(oh_d, alpha=1)
+    model.bert.exploit_cls_sparsity = True
+    assert torch.equal(dense_cam, sparse_cam), float((dense_cam - sparse_cam).abs().max())
+    for l, lay in enumerate(model.bert.encoder.layer):
+        assert torch.equal(lay.attention.self.get_attn_cam(), sparse_cams[l]), l
     out = gen.generate_LRP(input_ids=ids, attention_mask=torch.ones_like(mask), start_layer=0)
     _assert_map("bert_base.golden.nomask", out, g["map_nomask_sl0"], **LOOSE)
+
+
+# ------------------------------------------------------------------------------------------ full-size configs
+def _fits(bytes_needed):
+    free, total = torch.cuda.mem_get_info()
+    return bytes_needed < 0.8 * free
+
+
+def test_config2_vit_l16_384_batch32():
+    """BASELINE.json configs[2]: ViT-L/16 at 384^2 (N = 577, 24 blocks, 1024 wide, 16 heads), batch 32 on one MI355X.
+    Size-independent properties at the full size -- finite maps, LRP conservation (token relevance of every sample
+    sums to 1), batched == per-sample on the same cache (bitwise) -- plus the CPU oracle on ONE sample's slice of the
+    cached tensors (the oracle needs ~10 s per ViT-L sample)."""
+    from gpu_util import sliced_relprop_state
+    from transformer_explainability_amd import vit
+    from transformer_explainability_amd.generators import LRP
+    torch.manual_seed(0)
+    model = vit.vit_large_patch16_224(img_size=384).eval()
+    synthetic_init(model, 0)
+    model.to(dev())
+    lrp = LRP(model)
+    # probe the footprint at B = 4 before committing to B = 32 (a box driven out of memory is a strike)
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    lrp.generate_LRP(seeded_randn((4, 3, 384, 384), 3).to(dev()), start_layer=1)
+    torch.cuda.synchronize()
+    per_sample = (torch.cuda.max_memory_allocated() - base) / 4
+    B = 32
+    while B > 4 and not _fits(per_sample * B * 1.15):
+        B //= 2
+    record("vit_l16_384.memory", per_sample_gb=per_sample / 2 ** 30, batch=B)
+    for blk in model.blocks:      # drop the probe's caches before the big batch
+        blk.attn.attn = blk.attn.attn_cam = blk.attn.attn_gradients = None
+    torch.cuda.empty_cache()
+    x = seeded_randn((B, 3, 384, 384), 5).to(dev())
+    maps = lrp.generate_LRP(x, start_layer=1).clone()
+    assert maps.shape == (B, 576) and torch.isfinite(maps).all()
+    oh = _one_hot_of(model.head.Y.detach())
+    # oracle on sample 3's slice
+    i = 3
+    with sliced_relprop_state(model, i, B):
+        cache = vit_cache_from_model(model)
+        one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
+        assert torch.equal(one, maps[i:i + 1])
+    ref = O.vit_relprop(oh[i:i + 1].cpu(), cache, num_heads=16, start_layer=1)
+    _assert_map("vit_l16_384.oracle.map_sl1", maps[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)
+    # conservation over the whole batch
+    cam = model.head.relprop(oh, alpha=1)
+    cam = model.pool.relprop(cam.unsqueeze(1), alpha=1)
+    for blk in reversed(model.blocks):
+        cam = blk.relprop(cam, alpha=1)
+    sums = cam.double().sum(dim=(1, 2)).cpu()
+    record("vit_l16_384.conservation", min=float(sums.min()), max=float(sums.max()))
+    assert (sums - 1.0).abs().max() < 2e-3
+
+
+def test_config3_bert_base_512_batch32():
+    """BASELINE.json configs[3]: BERT-base, sequence length 512, batch 32, half of the batch padded (last 64 tokens
+    masked -> broadcast-mask Add rule).  Finite outputs, conservation, batched == per-sample on the same cache
+    (bitwise), oracle on one padded and one unpadded sample."""
+    from gpu_util import sliced_relprop_state
+    from transformer_explainability_amd import bert
+    from transformer_explainability_amd.generators import Generator
+    model = bert.BertForSequenceClassification(bert.BertConfigLite(num_labels=2)).eval()
+    synthetic_init(model, 0)
+    model.to(dev())
+    B, N = 32, 512
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1000, 20000, (B, N), generator=g).to(dev())
+    mask = torch.ones(B, N)
+    mask[::2, N - 64:] = 0
+    mask = mask.to(dev())
+    gen = Generator(model)
+    out = gen.generate_LRP(input_ids=ids, attention_mask=mask, start_layer=0).clone()
+    assert out.shape == (B, N) and torch.isfinite(out).all()
+    oh = _one_hot_of(model.classifier.Y.detach())
+    cam = model.relprop(oh, alpha=1)
+    sums = cam.double().sum(dim=(1, 2)).cpu()
+    record("bert_base_512.conservation", min=float(sums.min()), max=float(sums.max()))
+    assert (sums - 1.0).abs().max() < 2e-3
+    for i in (0, 1):       # padded, unpadded
+        with sliced_relprop_state(model, i, B):
+            cache = bert_cache_from_model(model)
+            model.relprop(oh[i:i + 1], alpha=1)
+            one = gen.attribution_tail(start_layer=0)
+            assert torch.equal(one, out[i:i + 1]), float((one - out[i:i + 1]).abs().max())
+        ref = O.bert_relprop(oh[i:i + 1].cpu(), cache, num_heads=12, start_layer=0)
+        _assert_map(f"bert_base_512.oracle.map_sl0.{i}", out[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)

@@ -220,6 +220,30 @@ def make_bert_module(L):
             cam = self.clone.relprop((cam1, cam2), **kwargs)
             return self.attention.relprop(cam, **kwargs)
 
+        def relprop_cls_only(self, cam_cls, **kwargs):
+            """BertLayer.relprop for relevance that lives on token 0 only (cam_cls [B,1,C]) -- the state right after
+            BertPooler.relprop (BERT.py:181-191), i.e. the LAST layer.  Every rule from output.add down to
+            attention.output.dense maps a zero relevance row to an exact zero row and Add's per-sample sums gain only
+            zeros from those rows, so these rules run on the [B,1,C] slice of their cached inputs; the result is
+            scattered into zero [B,N,C] tensors before the self-attention rules, which spread relevance to all
+            tokens.  Same values as the dense evaluation at 1/N of its Linear work (see vit.Block.relprop_cls_only)."""
+            alpha = kwargs.get("alpha", 1)
+            var = self.clone.variant
+            cls = lambda t: t[:, :1]                                             # noqa: E731
+            lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var)  # noqa: E731
+            c1, c2 = ops.add_relprop(cam_cls, cls(self.output.add.X[0]), cls(self.output.add.X[1]), variant=var)
+            c1 = lin(lin(c1, self.output.dense), self.intermediate.dense)
+            cam = ops.clone_relprop((c1, c2), cls(self.clone.X))
+            att = self.attention
+            a1, a2 = ops.add_relprop(cam, cls(att.output.add.X[0]), cls(att.output.add.X[1]), variant=var)
+            a1 = lin(a1, att.output.dense)
+            B, N, C = att.clone.X.shape
+            dense = torch.zeros((2, B, N, C), dtype=a1.dtype, device=a1.device)
+            dense[0, :, 0] = a1[:, 0]
+            dense[1, :, 0] = a2[:, 0]
+            cam1 = att.self.relprop(dense[0], **kwargs)
+            return att.clone.relprop((cam1, dense[1]), **kwargs)
+
     class BertEncoder(nn.Module):
         def __init__(self, config):
             super().__init__()
@@ -275,8 +299,20 @@ def make_bert_module(L):
             seq = self.encoder(emb, attention_mask=ext, head_mask=head_mask)[0]
             return (seq, self.pooler(seq))
 
+        exploit_cls_sparsity = True   # exact; set False to evaluate the last layer densely
+
         def relprop(self, cam, **kwargs):        # BERT.py:645-651
-            return self.encoder.relprop(self.pooler.relprop(cam, **kwargs), **kwargs)
+            if not self.exploit_cls_sparsity:
+                return self.encoder.relprop(self.pooler.relprop(cam, **kwargs), **kwargs)
+            # pooler.relprop puts relevance on token 0 only: keep it as a [B,1,C] row through the last layer's
+            # dense rules instead of a [B,N,C] tensor that is zero everywhere else
+            cam = self.pooler.dense.relprop(cam, **kwargs)
+            cam = ops.index_select_relprop(cam.unsqueeze(1), self.pooler.pool.X[:, :1], 0)
+            layers = list(self.encoder.layer)
+            cam = layers[-1].relprop_cls_only(cam, **kwargs)
+            for layer in reversed(layers[:-1]):
+                cam = layer.relprop(cam, **kwargs)
+            return cam
 
     class BertForSequenceClassification(nn.Module):
         def __init__(self, config):

@@ -110,10 +110,21 @@ __device__ __forceinline__ void store_kn_tile(float* __restrict__ lds, const f32
   }
 }
 
-// x+ = max(x, 0), x- = min(x, 0).  Builtins on purpose: hipcc pads the VALU-write -> MFMA-operand hazard for
-// instructions it knows, not for inline asm (an asm v_max_f32 here fed stale operands to the MFMAs).
-__device__ __forceinline__ float te_pos(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
-__device__ __forceinline__ float te_neg(float x) { return __builtin_amdgcn_fmed3f(x, -__builtin_inff(), 0.0f); }
+// x+ = max(x, 0), x- = min(x, 0) on the BIT PATTERN: as two's-complement integers, non-negative floats are >= 0 and
+// negative floats (sign bit set) are < 0, so v_max_i32(bits, 0) / v_min_i32(bits, 0) are the two clamps -- one VALU op
+// each, exact for every finite input (and -0.0 -> x+ = +0, x- = -0).  The float forms (fmaxf / v_med3_f32) cost an
+// extra canonicalising v_max_f32 x, x, x per operand under IEEE mode, i.e. 9 instead of 6 VALU ops per 4 MFMAs in
+// the Z-pass -- measured +3.4 % on the whole kernel pair: every VALU op in the MFMA stream costs ~3 MFMA-pipe cycles.
+// Plain C on purpose: hipcc pads the VALU-write -> MFMA-operand hazard for instructions it emits itself, not for
+// inline asm (an asm v_max_f32 here fed stale operands to the MFMAs).
+__device__ __forceinline__ float te_pos(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
+}
+__device__ __forceinline__ float te_neg(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b < 0 ? b : 0);
+}
 
 #define TE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
