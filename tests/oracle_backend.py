@@ -10,8 +10,8 @@ import torch
 from oracle import relprop_oracle as O
 
 
-def linear_relprop(R, X, W, alpha=1.0, variant="ours"):
-    return O.linear_relprop(R, X, W, alpha=alpha, variant=variant)
+def linear_relprop(R, X, W, alpha=1.0, variant="ours", Y=None, bias=None):
+    return O.linear_relprop(R, X, W, alpha=alpha, variant=variant)     # Y / bias: a device-side shortcut only
 
 
 def matmul_relprop_av(R, attn, v, out_scale=1.0, cam_v_out=None, variant="ours"):

@@ -232,6 +232,14 @@ def test_vit_b16_batch_equals_singles(vit_b16):
     assert torch.equal(dense, batch), float((dense - batch).abs().max())
     for l, blk in enumerate(model.blocks):
         assert torch.equal(blk.attn.get_attn_cam(), cams[l]), l
+    # Z-pass from the forward output (default) vs the reference-shaped two-GEMM Z-pass on the same cache
+    from transformer_explainability_amd import ops as _ops
+    _ops.USE_FORWARD_OUTPUT = False
+    try:
+        two_gemm = model.relprop(oh, method="transformer_attribution", start_layer=1, alpha=1)
+    finally:
+        _ops.USE_FORWARD_OUTPUT = True
+    _assert_map("vit_b16.zpass_from_forward_vs_two_gemm", batch, two_gemm, norm_tol=1e-4, rel_tol=1e-4)
     # micro-batches on separate HIP streams == the same micro-batches run one after the other, bitwise
     streamed = LRP(model, streams=2).generate_LRP(x, start_layer=1)
     halves = torch.cat([lrp.generate_LRP(x[:2], start_layer=1), lrp.generate_LRP(x[2:], start_layer=1)], 0)

@@ -134,6 +134,50 @@ def test_linear(simple, variant, T, in_f, out_f):
     check(f"linear_{variant}_{'simple' if simple else 'tiled'}({T},{in_f},{out_f})", got, ref, 2e-5)
 
 
+@pytest.mark.parametrize("T,in_f,out_f", LINEAR_SHAPES + [(788, 768, 768), (5, 3072, 768)])
+def test_linear_from_forward_output(T, in_f, out_f):
+    """Z-pass fed by the forward output Y = X W^T + b (te_linear_relprop_fwd_f32): Z = ((Y - b) + |X||W|^T) / 2 must
+    reproduce the oracle's X+W+^T + X-W-^T to GEMM-rounding accuracy; Y comes from rocBLAS (F.linear on the GPU)."""
+    from transformer_explainability_amd import ops
+    if in_f % 4 or out_f % 4:
+        pytest.skip("tiled kernels need in_f, out_f multiples of 4")
+    X, W, R = rnd((T, in_f), 21), rnd((out_f, in_f), 22, 0.05), rnd((T, out_f), 23, 0.01)
+    bias = rnd((out_f,), 24, 0.3)
+    X[0, :3] = 0.0
+    Xd, Wd, bd = X.to(dev()), W.to(dev()), bias.to(dev())
+    Y = torch.nn.functional.linear(Xd, Wd, bd)
+    got = ops.linear_relprop(R.to(dev()), Xd, Wd, alpha=1.0, variant="ours", Y=Y, bias=bd)
+    ref = O.linear_relprop(R, X, W, 1.0, "ours")
+    check(f"linear_fwd({T},{in_f},{out_f})", got, ref, 2e-5)
+    two = ops.linear_relprop(R.to(dev()), Xd, Wd, alpha=1.0, variant="ours")
+    check(f"linear_fwd_vs_two_gemm({T},{in_f},{out_f})", got, two, 2e-5)
+    got_nb = ops.linear_relprop(R.to(dev()), Xd, Wd, alpha=1.0, variant="ours", Y=torch.nn.functional.linear(Xd, Wd))
+    check(f"linear_fwd_nobias({T},{in_f},{out_f})", got_nb, ref, 2e-5)
+
+
+def test_linear_from_forward_output_cancellation():
+    """Where (Y - b) and |X||W|^T cancel the kernel must fall back to the plain positive-part sum:
+      * rows whose products are ALL negative (X > 0 against W rows < 0): reference Z = 0 exactly -> S = 0;
+      * rows with a single positive product of relative size 1e-6: Z tiny but exact;
+      * all-zero rows of X: Z = 0."""
+    from transformer_explainability_amd import ops
+    T, in_f, out_f = 140, 256, 192
+    X, W, R = rnd((T, in_f), 51), rnd((out_f, in_f), 52, 0.05), rnd((T, out_f), 53, 0.01)
+    X[:40] = X[:40].abs() + 0.01           # positive inputs ...
+    W[:50] = -W[:50].abs() - 0.001         # ... against negative weight rows: every product negative
+    X[40:45] = 0.0                         # zero rows
+    X[45:50] = X[45:50].abs() + 0.01
+    W[50:60] = -W[50:60].abs() - 0.001
+    W[50:60, 7] = 1e-6                     # one tiny positive product among negatives
+    bias = rnd((out_f,), 54, 0.3)
+    Xd, Wd, bd = X.to(dev()), W.to(dev()), bias.to(dev())
+    Y = torch.nn.functional.linear(Xd, Wd, bd)
+    got = ops.linear_relprop(R.to(dev()), Xd, Wd, alpha=1.0, variant="ours", Y=Y, bias=bd)
+    ref = O.linear_relprop(R, X, W, 1.0, "ours")
+    assert torch.isfinite(got).all()
+    check("linear_fwd_cancellation", got, ref, 2e-5)
+
+
 @pytest.mark.parametrize("simple", [False, True], ids=["tiled", "simple"])
 @pytest.mark.parametrize("variant", ["ours", "lrp"])
 def test_linear_alpha2(simple, variant):

@@ -33,6 +33,8 @@ SIGNATURES = {
     "te_linear_relprop_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_linear_zpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "te_linear_cpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "te_linear_zpass_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "te_linear_relprop_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     "te_matmul_relprop_av_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64]),
     "te_matmul_relprop_av_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
                                       _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),

@@ -230,7 +230,8 @@ def make_bert_module(L):
             alpha = kwargs.get("alpha", 1)
             var = self.clone.variant
             cls = lambda t: t[:, :1]                                             # noqa: E731
-            lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var)  # noqa: E731
+            lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,     # noqa: E731
+                                                  Y=cls(m.Y), bias=m.bias)
             c1, c2 = ops.add_relprop(cam_cls, cls(self.output.add.X[0]), cls(self.output.add.X[1]), variant=var)
             c1 = lin(lin(c1, self.output.dense), self.intermediate.dense)
             cam = ops.clone_relprop((c1, c2), cls(self.clone.X))

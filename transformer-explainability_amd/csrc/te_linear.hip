@@ -6,6 +6,14 @@
 //   K2 ("C-pass",  NN GEMM, K = out_f): P+[t,i] = sum_j S[t,j] W+[j,i] ; P-[t,i] = sum_j S[t,j] W-[j,i]
 //                                       out = X+ . P+ + X- . P-                      (epilogue)
 //
+//   K1f ("Z-pass from the forward output", variant ours, alpha = 1): with Y = X W^T + b cached by the forward pass
+//        (forward_hook stores self.Y, layers_ours.py:16-27)   X+W+^T + X-W-^T = ( (Y - b) + |X||W|^T ) / 2,
+//        because the same-sign products sum to Z and the opposite-sign ones to XW^T - Z, while |X||W|^T is their
+//        difference.  ONE GEMM (|X||W|^T, K = in_f) instead of two; where the two halves cancel (Z < 2^-7 |X||W|^T:
+//        nearly every product negative) the element is recomputed as the plain positive-part sum, so exact zeros and
+//        tiny Z behave like the reference.  Measured on ViT-B maps: moves the result by 3-8e-7 relative, the same as
+//        permuting the summation order of the two-GEMM form (profiles/r01_zpass_from_forward_probe.log).
+//
 // The positive / negative parts are formed in registers right before the MFMA (one VALU op on the fragment that
 // was just read from LDS), so X, W and S are each staged through LDS exactly once and no clamped copy of W or X
 // ever exists in HBM.  v_mfma_f32_32x32x2_f32 is an exact-f32 k-ordered fma chain (MI355X guide), i.e.
@@ -126,6 +134,8 @@ __device__ __forceinline__ float te_neg(float x) {
   return __int_as_float(b < 0 ? b : 0);
 }
 
+__device__ __forceinline__ float te_abs(float x) { return __int_as_float(__float_as_int(x) & 0x7fffffff); }
+
 #define TE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 struct TileCoord {
@@ -145,12 +155,29 @@ __device__ __forceinline__ TileCoord tile_coord(int v, int ntiles, int nbn) {
 
 // ------------------------------------------------------------------------------------------------
 // K1: S = sd(R, X+ W+^T + X- W-^T)        SWAP exchanges W+ / W- (inhibitor term, beta != 0)
-//     LRP: S1 = sd(R, X+ W+^T), S2 = sd(R, X- W-^T) kept apart (layers_lrp.py:199-200)
+//     ZM_LRP: S1 = sd(R, X+ W+^T), S2 = sd(R, X- W-^T) kept apart (layers_lrp.py:199-200)
+//     ZM_FWD: S = sd(R, ((Y - bias) + |X| |W|^T) / 2)  -- one product; Y = forward output, bias may be NULL
 // ------------------------------------------------------------------------------------------------
-template <bool LRP, bool SWAP, int BM, int BN>
+enum { ZM_OURS = 0, ZM_LRP = 1, ZM_FWD = 2 };
+constexpr float kCancelTol = 0.0078125f;   // 2^-7: below this share of |X||W|^T the split sum is recomputed exactly
+
+// plain positive-part sum of one output element (the reference's Z), k-ordered
+__device__ __noinline__ float exact_z(const float* __restrict__ x, const float* __restrict__ w, int64_t K) {
+  float z1 = 0.0f, z2 = 0.0f;
+  for (int64_t k = 0; k < K; ++k) {
+    const float xv = x[k], wv = w[k];
+    z1 = fmaf(fmaxf(xv, 0.0f), fmaxf(wv, 0.0f), z1);
+    z2 = fmaf(fminf(xv, 0.0f), fminf(wv, 0.0f), z2);
+  }
+  return z1 + z2;
+}
+
+template <int ZM, bool SWAP, int BM, int BN>
 __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ R,
+    const float* __restrict__ Y, const float* __restrict__ bias,
     float* __restrict__ S1, float* __restrict__ S2, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles) {
+  constexpr bool LRP = (ZM == ZM_LRP), FWD = (ZM == ZM_FWD);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MI = BM / 64, NI = BN / 64;   // 32x32 MFMA blocks per wave
   constexpr int WM = BM / 2, WN = BN / 2;     // rows / columns per wave
@@ -163,6 +190,7 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
   const int lr = lane & 31, kh = lane >> 5;
 
   constexpr int NACC = LRP ? 2 : 1;
+  static_assert(!(FWD && SWAP), "the forward-output Z-pass has no inhibitor form");
   f32x16 acc[NACC][MI][NI];
 #pragma unroll
   for (int s = 0; s < NACC; ++s)
@@ -198,28 +226,40 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
         b[ni] = *reinterpret_cast<const f32x4*>(b_tile + swz(wn * WN + ni * 32 + lr, kg * 2 + kh));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float ap[MI], an[MI], bp[NI], bn[NI];
+        if constexpr (FWD) {
+          float aa[MI], ab[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          ap[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_pos(a[mi][j]);
-          an[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_neg(a[mi][j]);
+          for (int mi = 0; mi < MI; ++mi) aa[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_abs(a[mi][j]);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) ab[ni] = (TE_ABLATION == 2) ? b[ni][j] : te_abs(b[ni][j]);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(aa[mi], ab[ni], acc[0][mi][ni]);
+        } else {
+          float ap[MI], an[MI], bp[NI], bn[NI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            ap[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_pos(a[mi][j]);
+            an[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_neg(a[mi][j]);
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const float p = (TE_ABLATION == 2) ? b[ni][j] : te_pos(b[ni][j]);
+            const float n = (TE_ABLATION == 2) ? b[ni][j] : te_neg(b[ni][j]);
+            bp[ni] = SWAP ? n : p;   // partner of X+
+            bn[ni] = SWAP ? p : n;   // partner of X-
+          }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(ap[mi], bp[ni], acc[0][mi][ni]);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[NACC - 1][mi][ni] = TE_MFMA(an[mi], bn[ni], acc[NACC - 1][mi][ni]);
         }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const float p = (TE_ABLATION == 2) ? b[ni][j] : te_pos(b[ni][j]);
-          const float n = (TE_ABLATION == 2) ? b[ni][j] : te_neg(b[ni][j]);
-          bp[ni] = SWAP ? n : p;   // partner of X+
-          bn[ni] = SWAP ? p : n;   // partner of X-
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(ap[mi], bp[ni], acc[0][mi][ni]);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[NACC - 1][mi][ni] = TE_MFMA(an[mi], bn[ni], acc[NACC - 1][mi][ni]);
       }
     }
   };
@@ -271,8 +311,14 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
             if constexpr (LRP) {
               S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
               S2[gr * Nn + gc] = te_sd(r, acc[1][mi][ni][e]);
+            } else if constexpr (FWD) {
+              const float a_abs = acc[0][mi][ni][e];                          // |X| |W|^T  >= 0
+              const float lin = Y[gr * Nn + gc] - (bias ? bias[gc] : 0.0f);   // X W^T
+              float z = 0.5f * (lin + a_abs);
+              if (!(z > kCancelTol * a_abs)) z = exact_z(X + gr * K, W + gc * K, K);   // cancellation / all-zero row
+              S1[gr * Nn + gc] = te_sd(r, z);
             } else {
-              S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
+              S1[gr * Nn + gc] = (TE_ABLATION == 3) ? r * acc[0][mi][ni][e] : te_sd(r, acc[0][mi][ni][e]);
             }
           }
 #pragma unroll
@@ -507,7 +553,7 @@ enum Tile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2 };
 // last round: 12,608 x 768 outputs are 594 tiles of 128x128 = 2.32 per CU (the third round a third full) but 1188
 // of 128x64 = 4.64 per CU.  Estimated chip efficiency of a tile = (tiles / CUs) / ceil(tiles / CUs) x a per-tile
 // factor; the best estimate wins.  TE_LINEAR_TILE = 128x128 | 128x64 | 64x64 pins the choice (tuning).
-inline Tile pick_tile(int64_t T, int64_t n_out) {
+inline Tile pick_tile(int64_t T, int64_t n_out, bool one_product = false) {
   static const int pinned = [] {
     const char* e = getenv("TE_LINEAR_TILE");
     if (!e) return -1;
@@ -521,7 +567,9 @@ inline Tile pick_tile(int64_t T, int64_t n_out) {
     const int64_t tiles = te_ceil_div(T, bm) * te_ceil_div(n_out, bn);
     return factor * ((double)tiles / kCUs) / (double)te_ceil_div(tiles, kCUs);
   };
-  const double e0 = eff(128, 128, 1.0), e1 = eff(128, 64, 0.98), e2 = eff(64, 64, 0.93);
+  // the one-product Z-pass has half the MFMAs per K-step: the wide tile's second co-resident block no longer covers
+  // its barriers (measured 80 vs 90 TF at out_f = 2304)
+  const double e0 = eff(128, 128, one_product ? 0.85 : 1.0), e1 = eff(128, 64, 0.98), e2 = eff(64, 64, 0.93);
   if (e2 > e1 && e2 > e0) return TILE_64x64;
   return (e1 > e0) ? TILE_128x64 : TILE_128x128;
 }
@@ -539,15 +587,15 @@ inline int grid_for(int ntiles) {
   return ntiles < kCUs * per_cu ? ntiles : kCUs * per_cu;
 }
 
-template <bool LRP, bool SWAP, int BM, int BN>
-inline void launch_k1(const float* X, const float* W, const float* R, float* S1, float* S2, int64_t T, int64_t in_f,
-                      int64_t out_f, hipStream_t stream) {
+template <int ZM, bool SWAP, int BM, int BN>
+inline void launch_k1(const float* X, const float* W, const float* R, const float* Y, const float* bias, float* S1,
+                      float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream) {
   const int nbn = (int)te_ceil_div(out_f, BN);
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k1_lds<BM, BN>();
-  allow_lds(linear_k1_kernel<LRP, SWAP, BM, BN>, lds);
-  linear_k1_kernel<LRP, SWAP, BM, BN><<<dim3((unsigned)grid_for<lds>(ntiles)), dim3(kThreads), lds, stream>>>(
-      X, W, R, S1, S2, T, in_f, out_f, nbn, ntiles);
+  allow_lds(linear_k1_kernel<ZM, SWAP, BM, BN>, lds);
+  linear_k1_kernel<ZM, SWAP, BM, BN><<<dim3((unsigned)grid_for<lds>(ntiles)), dim3(kThreads), lds, stream>>>(
+      X, W, R, Y, bias, S1, S2, T, in_f, out_f, nbn, ntiles);
 }
 template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
 inline void launch_k2(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
@@ -587,7 +635,7 @@ int run_half(const float* R, const float* X, const float* W, float* out, int64_t
   const Tile t1 = pick_tile(T, out_f), t2 = pick_tile(T, in_f);
   if (lrp) {
     // the lrp variant's K1 holds two accumulator sets; out - beta*(C1 + C2) is formed in two accumulate steps
-#define TE_K1(BM_, BN_) launch_k1<true, SWAP, BM_, BN_>(X, W, R, S1, S2, T, in_f, out_f, stream)
+#define TE_K1(BM_, BN_) launch_k1<ZM_LRP, SWAP, BM_, BN_>(X, W, R, nullptr, nullptr, S1, S2, T, in_f, out_f, stream)
     TE_DISPATCH_TILE(t1, TE_K1);
 #undef TE_K1
 #define TE_K2(BM_, BN_)                                                                   \
@@ -596,7 +644,7 @@ int run_half(const float* R, const float* X, const float* W, float* out, int64_t
     TE_DISPATCH_TILE(t2, TE_K2);
 #undef TE_K2
   } else {
-#define TE_K1(BM_, BN_) launch_k1<false, SWAP, BM_, BN_>(X, W, R, S1, S1, T, in_f, out_f, stream)
+#define TE_K1(BM_, BN_) launch_k1<ZM_OURS, SWAP, BM_, BN_>(X, W, R, nullptr, nullptr, S1, S1, T, in_f, out_f, stream)
     TE_DISPATCH_TILE(t1, TE_K1);
 #undef TE_K1
 #define TE_K2(BM_, BN_) launch_k2<0, SWAP, ACCUM, BM_, BN_>(S1, W, X, out, T, in_f, out_f, scale, stream)
@@ -617,7 +665,7 @@ extern "C" int te_linear_zpass_f32(const float* R, const float* X, const float* 
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(R) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(S))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-#define TE_K1(BM_, BN_) launch_k1<false, false, BM_, BN_>(X, W, R, S, S, T, in_f, out_f, stream)
+#define TE_K1(BM_, BN_) launch_k1<ZM_OURS, false, BM_, BN_>(X, W, R, nullptr, nullptr, S, S, T, in_f, out_f, stream)
   TE_DISPATCH_TILE(pick_tile(T, out_f), TE_K1);
 #undef TE_K1
   TE_RETURN_IF_LAUNCH_FAILED();
@@ -635,6 +683,34 @@ extern "C" int te_linear_cpass_f32(const float* S, const float* X, const float* 
 #undef TE_K2
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
+}
+
+// ---- Z-pass from the forward output (see K1f in the file header), alone and composed with the C-pass
+extern "C" int te_linear_zpass_fwd_f32(const float* R, const float* X, const float* W, const float* Y,
+                                       const float* bias, float* S, int64_t T, int64_t in_f, int64_t out_f,
+                                       te_stream_t stream_) {
+  if (!R || !X || !W || !Y || !S || T <= 0 || in_f <= 0 || out_f <= 0) return TE_ERR_INVALID_ARG;
+  if ((in_f % 4) || (out_f % 4) || !te_aligned16(R) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(S))
+    return TE_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+#define TE_K1(BM_, BN_) launch_k1<ZM_FWD, false, BM_, BN_>(X, W, R, Y, bias, S, S, T, in_f, out_f, stream)
+  TE_DISPATCH_TILE(pick_tile(T, out_f, true), TE_K1);
+#undef TE_K1
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+extern "C" int te_linear_relprop_fwd_f32(const float* R, const float* X, const float* W, const float* Y,
+                                         const float* bias, float* out, int64_t T, int64_t in_f, int64_t out_f,
+                                         void* ws, size_t ws_bytes, te_stream_t stream_) {
+  if (!R || !X || !W || !Y || !out || T <= 0 || in_f <= 0 || out_f <= 0) return TE_ERR_INVALID_ARG;
+  if (!ws || ws_bytes < te_linear_relprop_workspace_bytes(T, in_f, out_f, TE_VARIANT_OURS)) return TE_ERR_WORKSPACE;
+  if (!te_aligned16(ws)) return TE_ERR_WORKSPACE;
+  if ((in_f % 4) || (out_f % 4) || !te_aligned16(R) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(out))
+    return TE_ERR_UNSUPPORTED;   // callers fall back to te_linear_relprop_f32 (any shape)
+  int rc = te_linear_zpass_fwd_f32(R, X, W, Y, bias, (float*)ws, T, in_f, out_f, stream_);
+  if (rc != TE_OK) return rc;
+  return te_linear_cpass_f32((const float*)ws, X, W, out, T, in_f, out_f, stream_);
 }
 
 extern "C" size_t te_linear_relprop_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f, int variant) {

@@ -73,8 +73,16 @@ class _on_device:
 
 
 # ---------------------------------------------------------------------------------------- a3
-def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant="ours") -> Tensor:
-    """Linear.relprop: R [..., out], X [..., in], W [out, in] -> [..., in]."""
+# Linear.relprop obtains Z from the forward output when the caller supplies it (te_linear_relprop_fwd_f32): one GEMM
+# less per rule.  Tests flip this to run the two-GEMM Z-pass on the same inputs.
+USE_FORWARD_OUTPUT = True
+
+
+def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant="ours",
+                   Y: Optional[Tensor] = None, bias: Optional[Tensor] = None) -> Tensor:
+    """Linear.relprop: R [..., out], X [..., in], W [out, in] -> [..., in].
+    Y [..., out] (optional) is the forward output F.linear(X, W, bias) the rule module cached as self.Y; with it
+    (variant ours, alpha = 1) the Z-pass needs one product instead of two."""
     out_f, in_f = W.shape
     lead = X.shape[:-1]
     Rc, Xc, Wc = _c(R).reshape(-1, out_f), _c(X).reshape(-1, in_f), _c(W)
@@ -83,23 +91,40 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
         raise _lib.TeError(f"Linear.relprop: R has {Rc.shape[0]} rows, X has {T}")
     out = torch.empty((T, in_f), dtype=torch.float32, device=X.device)
     var = _variant(variant)
-    if KERNEL_TIMER is not None and var == TE_VARIANT_OURS and alpha == 1 and in_f % 4 == 0 and out_f % 4 == 0:
+    fast_ok = var == TE_VARIANT_OURS and alpha == 1 and in_f % 4 == 0 and out_f % 4 == 0
+    fwd = fast_ok and USE_FORWARD_OUTPUT and Y is not None
+    if fwd:
+        Yc = _c(Y.detach()).reshape(-1, out_f)
+        bc = None if bias is None else _c(bias.detach())
+        if Yc.shape[0] != T:
+            raise _lib.TeError(f"Linear.relprop: Y has {Yc.shape[0]} rows, X has {T}")
+    if KERNEL_TIMER is not None and fast_ok:
         # bench.py roofline probe: same two kernels, launched one by one so that each launch can be
         # bracketed by HIP events on the stream it runs on
         with _on_device(Xc) as lib:
             S = torch.empty((T, out_f), dtype=torch.float32, device=X.device)
             st = _stream(Xc)
-            with KERNEL_TIMER("linear_zpass", 2.0 * T * (2 * in_f) * out_f):
-                _lib.check(lib.te_linear_zpass_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(S), T, in_f, out_f, st),
-                           "te_linear_zpass_f32")
+            if fwd:
+                with KERNEL_TIMER("linear_zpass_fwd", 2.0 * T * in_f * out_f):
+                    _lib.check(lib.te_linear_zpass_fwd_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(Yc), _ptr(bc), _ptr(S), T,
+                                                           in_f, out_f, st), "te_linear_zpass_fwd_f32")
+            else:
+                with KERNEL_TIMER("linear_zpass", 2.0 * T * (2 * in_f) * out_f):
+                    _lib.check(lib.te_linear_zpass_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(S), T, in_f, out_f, st),
+                               "te_linear_zpass_f32")
             with KERNEL_TIMER("linear_cpass", 2.0 * T * (2 * in_f) * out_f):
                 _lib.check(lib.te_linear_cpass_f32(_ptr(S), _ptr(Xc), _ptr(Wc), _ptr(out), T, in_f, out_f, st),
                            "te_linear_cpass_f32")
         return out.reshape(*lead, in_f)
     with _on_device(Xc) as lib:
         ws = _ws(lib.te_linear_relprop_workspace_bytes(T, in_f, out_f, var), Xc)
-        _lib.check(lib.te_linear_relprop_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(out), T, in_f, out_f, float(alpha),
-                                             var, _ptr(ws), ws.numel(), _stream(Xc)), "te_linear_relprop_f32")
+        if fwd:
+            _lib.check(lib.te_linear_relprop_fwd_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(Yc), _ptr(bc), _ptr(out), T, in_f,
+                                                     out_f, _ptr(ws), ws.numel(), _stream(Xc)),
+                       "te_linear_relprop_fwd_f32")
+        else:
+            _lib.check(lib.te_linear_relprop_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(out), T, in_f, out_f, float(alpha),
+                                                 var, _ptr(ws), ws.numel(), _stream(Xc)), "te_linear_relprop_f32")
     return out.reshape(*lead, in_f)
 
 

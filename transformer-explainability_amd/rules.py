@@ -91,7 +91,11 @@ class Linear(nn.Linear, RelProp):
     """layers_ours.py:207-230 / layers_lrp.py:188-211 -> te_linear_relprop_f32."""
 
     def relprop(self, R, alpha):
-        return ops.linear_relprop(R, self.X, self.weight.detach(), alpha=alpha, variant=self.variant)
+        # self.Y (the forward output, cached by forward_hook like the reference does) lets the kernel derive
+        # Z = X+ W+^T + X- W-^T from one product instead of two
+        Y = self.Y if (torch.is_tensor(getattr(self, "Y", None)) and self.Y.shape[:-1] == self.X.shape[:-1]) else None
+        return ops.linear_relprop(R, self.X, self.weight.detach(), alpha=alpha, variant=self.variant, Y=Y,
+                                  bias=self.bias)
 
 
 class Add(RelProp):

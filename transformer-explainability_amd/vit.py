@@ -156,11 +156,12 @@ def make_vit_module(L):
             var = self.add2.variant
             cls = lambda t: t[:, :1]                                             # noqa: E731
             c1, c2 = ops.add_relprop(cam_cls, cls(self.add2.X[0]), cls(self.add2.X[1]), variant=var)
-            c2 = ops.linear_relprop(c2, cls(self.mlp.fc2.X), self.mlp.fc2.weight.detach(), alpha=alpha, variant=var)
-            c2 = ops.linear_relprop(c2, cls(self.mlp.fc1.X), self.mlp.fc1.weight.detach(), alpha=alpha, variant=var)
+            lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,     # noqa: E731
+                                                  Y=cls(m.Y), bias=m.bias)
+            c2 = lin(lin(c2, self.mlp.fc2), self.mlp.fc1)
             cam = ops.clone_relprop((c1, c2), cls(self.clone2.X))
             c1, c2 = ops.add_relprop(cam, cls(self.add1.X[0]), cls(self.add1.X[1]), variant=var)
-            c2 = ops.linear_relprop(c2, cls(self.attn.proj.X), self.attn.proj.weight.detach(), alpha=alpha, variant=var)
+            c2 = lin(c2, self.attn.proj)
             B, N, C = self.clone1.X.shape
             dense = torch.zeros((2, B, N, C), dtype=c2.dtype, device=c2.device)
             dense[0, :, 0] = c1[:, 0]
