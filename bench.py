@@ -9,7 +9,9 @@ A "step" = one pass of the hot path over one batch of synthetic images already r
 stock PyTorch-ROCm forward + attention-gradient backward, then the HIP relprop rules, the
 gradient x relevance head-mean and the rollout chain (LRP.generate_LRP, method
 "transformer_attribution", start_layer 1 as baselines/ViT/imagenet_seg_eval.py:196 of the reference calls
-it).  Nothing is skipped: all 12 blocks are propagated, fp32 end to end.
+it), fp32 end to end.  All 12 blocks are propagated; the only shortcuts are exact or rounding-level:
+the inhibitor half is dead at alpha = 1, the last block's dense rules run on the class-token row they are confined to,
+and the Z-pass of Linear.relprop reuses the forward output X W^T + b instead of recomputing it.
 
 Weak scaling: every rank runs the same batch size on its own images; the only communication is one
 all_gather (RCCL) of the finished [B,196] maps of the last step, inside the timed region.
@@ -262,7 +264,7 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         cp = timer.summary("linear_cpass")
-        zp = timer.summary("linear_zpass")
+        zp = timer.summary("linear_zpass_fwd") or timer.summary("linear_zpass")
         if cp:
             roof = {"bound": "mfma", "kernel": "linear_k2_kernel<0,false,false> (Linear.relprop C-pass)",
                     "achieved": cp["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -271,7 +273,8 @@ def main():
                                     "FETCH_SIZE / WRITE_SIZE passes (profiles/r01_linear_traffic_pmc.json)",
                     "launches_timed": cp["launches"], "avg_launch_us": cp["avg_us"],
                     "algorithmic_flops_per_launch_avg": cp["flops_per_launch_avg"],
-                    "zpass": {"achieved": zp["tflops"], "avg_launch_us": zp["avg_us"]} if zp else None}
+                    "zpass": {"kernel": "linear_k1_kernel<ZM_FWD> (Z-pass from the forward output, 2*T*in*out FLOP)",
+                              "achieved": zp["tflops"], "avg_launch_us": zp["avg_us"]} if zp else None}
         line["roofline"] = roof
         base = None
         if world == 1 and args.cpu_baseline != "off":
