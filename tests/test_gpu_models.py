@@ -244,6 +244,14 @@ def test_vit_b16_batch_equals_singles(vit_b16):
     streamed = LRP(model, streams=2).generate_LRP(x, start_layer=1)
     halves = torch.cat([lrp.generate_LRP(x[:2], start_layer=1), lrp.generate_LRP(x[2:], start_layer=1)], 0)
     assert torch.equal(streamed, halves), float((streamed - halves).abs().max())
+    # the whole pass replayed from a HIP graph == the eager pass, bitwise (same kernels, same order), on new inputs too
+    from transformer_explainability_amd.generators import GraphedLRP
+    glrp = GraphedLRP(lrp, x, method="transformer_attribution", start_layer=1)
+    assert torch.equal(glrp(x), batch)
+    x2 = seeded_randn((B, 3, 224, 224), 8).to(dev())
+    replayed = glrp(x2).clone()
+    assert torch.equal(replayed, lrp.generate_LRP(x2, start_layer=1))
+    del glrp
     singles = torch.cat([lrp.generate_LRP(x[i:i + 1], start_layer=1) for i in range(B)], 0)
     _assert_map("vit_b16.batch_vs_separate_forwards", batch, singles, **LOOSE)
     # LRP conservation: the token relevance of every sample sums to 1

@@ -267,9 +267,10 @@ def make_bert_module(L):
             self.dense = L.Linear(config.hidden_size, config.hidden_size)
             self.activation = L.Tanh()
             self.pool = L.IndexSelect()
+            self.register_buffer("_cls_index", torch.zeros((), dtype=torch.long), persistent=False)
 
         def forward(self, hidden_states):
-            first = self.pool(hidden_states, 1, torch.tensor(0, device=hidden_states.device)).squeeze(1)
+            first = self.pool(hidden_states, 1, self._cls_index).squeeze(1)
             return self.activation(self.dense(first))
 
         def relprop(self, cam, **kwargs):        # BERT.py:181-191 (tanh rule = identity)

@@ -172,13 +172,13 @@ class IndexSelect(RelProp):
     def forward(self, inputs, dim, indices):
         self.__setattr__('dim', dim)
         self.__setattr__('indices', indices)
-        return torch.index_select(inputs, dim, indices)
+        return torch.index_select(inputs, dim, indices.reshape(-1) if torch.is_tensor(indices) else indices)
 
     def relprop(self, R, alpha):
         idx = self.indices
         if self.dim != 1 or self.X.dim() != 3 or (torch.is_tensor(idx) and idx.numel() != 1):
             raise NotImplementedError("IndexSelect.relprop: only dim=1 with a single index is accelerated")
-        return ops.index_select_relprop(R, self.X, int(idx))
+        return ops.index_select_relprop(R, self.X, int(idx))      # (device sync if idx lives on the GPU)
 
 
 class Sequential(nn.Sequential):

@@ -216,6 +216,7 @@ def make_vit_module(L):
             self.add = L.Add()
             self.inp_grad = None
             self.exploit_cls_sparsity = True     # exact; set False to evaluate the last block densely
+            self.register_buffer("_cls_index", torch.zeros((), dtype=torch.long), persistent=False)
 
         def save_inp_grad(self, grad): self.inp_grad = grad
         def get_inp_grad(self): return self.inp_grad
@@ -243,7 +244,7 @@ def make_vit_module(L):
             for blk in self.blocks:
                 x = blk(x)
             x = self.norm(x)
-            x = self.pool(x, dim=1, indices=torch.tensor(0, device=x.device)).squeeze(1)
+            x = self.pool(x, dim=1, indices=self._cls_index).squeeze(1)   # (a device tensor made once: graph-capturable)
             return self.head(x)
 
         # ------------------------------------------------------------------------------------------
