@@ -116,6 +116,26 @@ int te_matmul_relprop_av_f32(const float* R, int64_t r_sb, int64_t r_sh, int64_t
                              int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
                              void* ws, size_t ws_bytes, te_stream_t stream);
 size_t te_matmul_relprop_qk_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t D);
+/* The same two rules with Z supplied by the caller: Z is the FORWARD output of the product whose rule is evaluated
+ * (einsum / MatMul modules cache it as self.Y, forward_hook layers_ours.py:16-27; contiguous [B,H,N,D] for AV,
+ * [B,H,N,N] = unscaled q k^T for QK).  The reference's autograd re-evaluates that product and gets the same bits, so
+ * the rule needs two products instead of three and S matches the forward pass exactly.  Z == NULL computes it. */
+int te_matmul_relprop_av_fwd_f32(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn,
+                                 const float* attn,
+                                 const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                                 const float* Z,
+                                 float* cam_attn,
+                                 float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
+                                 int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
+                                 void* ws, size_t ws_bytes, te_stream_t stream);
+int te_matmul_relprop_qk_fwd_f32(const float* R_nn,
+                                 const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                                 const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                 const float* Z,
+                                 float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
+                                 float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
+                                 int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
+                                 void* ws, size_t ws_bytes, te_stream_t stream);
 int te_matmul_relprop_qk_f32(const float* R_nn,
                              const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
                              const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,

@@ -23,7 +23,10 @@ def vit_cache_from_model(model):
             "proj_x": _cpu(blk.attn.proj.X), "proj_w": _cpu(blk.attn.proj.weight),
             "attn": _cpu(blk.attn.get_attn()), "attn_grad": _cpu(blk.attn.get_attn_gradients()),
             "qkv_out": _cpu(blk.attn.qkv.Y), "qkv_x": _cpu(blk.attn.qkv.X), "qkv_w": _cpu(blk.attn.qkv.weight),
-            "clone1_x": _cpu(blk.clone1.X)})
+            "clone1_x": _cpu(blk.clone1.X),
+            # the attention products as the forward pass computed them (what the reference's autograd re-evaluation
+            # reproduces on that device): unscaled q k^T and attn v
+            "z_qk": _cpu(getattr(blk.attn.matmul1, "Y", None)), "z_av": _cpu(getattr(blk.attn.matmul2, "Y", None))})
     return {"head_x": _cpu(model.head.X), "head_w": _cpu(model.head.weight), "pool_x": _cpu(model.pool.X),
             "blocks": blocks}
 
@@ -46,7 +49,8 @@ def bert_cache_from_model(model):
             "ext_mask": _cpu(sa.add.X[1]) if masked else None,
             "q_x": _cpu(sa.query.X), "q_w": _cpu(sa.query.weight), "k_x": _cpu(sa.key.X), "k_w": _cpu(sa.key.weight),
             "v_x": _cpu(sa.value.X), "v_w": _cpu(sa.value.weight),
-            "self_clone_x": _cpu(sa.clone.X), "att_clone_x": _cpu(lay.attention.clone.X)})
+            "self_clone_x": _cpu(sa.clone.X), "att_clone_x": _cpu(lay.attention.clone.X),
+            "z_qk": _cpu(getattr(sa.matmul1, "Y", None)), "z_av": _cpu(getattr(sa.matmul2, "Y", None))})
     return {"cls_x": _cpu(model.classifier.X), "cls_w": _cpu(model.classifier.weight),
             "pool_dense_x": _cpu(model.bert.pooler.dense.X), "pool_dense_w": _cpu(model.bert.pooler.dense.weight),
             "pool_x": _cpu(model.bert.pooler.pool.X), "layers": layers}

@@ -85,31 +85,36 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant:
 # a4  einsum / MatMul relprop (RelPropSimple)       modules/layers_ours.py:48-60,122-127
 #                                                   BERT_explainability/modules/layers_ours.py:89-91
 # --------------------------------------------------------------------------------------------
-def matmul_relprop(R: Tensor, X0: Tensor, X1: Tensor) -> Tuple[Tensor, Tensor]:
+def matmul_relprop(R: Tensor, X0: Tensor, X1: Tensor, z: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Generic batched rule for ``Z = X0 @ X1`` (X0 [..., M, K], X1 [..., K, N], R [..., M, N]).
 
     out0 = X0 * (S @ X1^T), out1 = X1 * (X0^T @ S), S = safe_divide(R, Z).  The callers halve both
     outputs (ViT_LRP.py:161-162,172-173; BERT.py:373-374,392-393); that is NOT done here.
+
+    ``z``: the reference obtains Z by re-running the module's forward inside autograd
+    (layers_ours.py:49-52), which reproduces the forward output bit for bit on the device it runs on.  When the
+    cached inputs come from another device (a GPU forward checked on the CPU) that forward output is itself one
+    of the inputs; pass it as ``z`` so that the rule is evaluated on what the reference would have seen there.
     """
-    Z = X0.matmul(X1)
+    Z = X0.matmul(X1) if z is None else z
     S = safe_divide(R, Z)
     out0 = X0 * S.matmul(X1.transpose(-1, -2))
     out1 = X1 * X0.transpose(-1, -2).matmul(S)
     return out0, out1
 
 
-def einsum_av_relprop(R: Tensor, attn: Tensor, v: Tensor) -> Tuple[Tensor, Tensor]:
+def einsum_av_relprop(R: Tensor, attn: Tensor, v: Tensor, z: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """einsum('bhij,bhjd->bhid').relprop  (ViT_LRP.py:160): returns (cam_attn, cam_v), un-halved."""
-    return matmul_relprop(R, attn, v)
+    return matmul_relprop(R, attn, v, z)
 
 
-def einsum_qk_relprop(R: Tensor, q: Tensor, k: Tensor) -> Tuple[Tensor, Tensor]:
+def einsum_qk_relprop(R: Tensor, q: Tensor, k: Tensor, z: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """einsum('bhid,bhjd->bhij').relprop  (ViT_LRP.py:171): returns (cam_q, cam_k), un-halved.
 
     The second operand of the einsum is k [B,H,N,D] (not transposed), so the second output has
     k's shape: cam_k = k * (S^T @ q).
     """
-    Z = q.matmul(k.transpose(-1, -2))
+    Z = q.matmul(k.transpose(-1, -2)) if z is None else z
     S = safe_divide(R, Z)
     cam_q = q * S.matmul(k)
     cam_k = k * S.transpose(-1, -2).matmul(q)
@@ -244,6 +249,8 @@ def vit_block_relprop(cam: Tensor, blk: dict, num_heads: int, alpha: float = 1.0
 
       add2_x0, add2_x1, fc2_x, fc2_w, fc1_x, fc1_w, clone2_x, add1_x0, add1_x1, proj_x, proj_w,
       attn [B,H,N,N], qkv_out [B,N,3C] (output of the qkv Linear), qkv_x, qkv_w, clone1_x
+      optional z_av [B,H,N,D], z_qk [B,H,N,N]: the two attention products as the forward pass computed them
+      (see matmul_relprop)
 
     Returns (cam, attn_cam).
     """
@@ -257,11 +264,11 @@ def vit_block_relprop(cam: Tensor, blk: dict, num_heads: int, alpha: float = 1.0
     B, N, C = cam2.shape
     qkv = blk["qkv_out"].reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    c_attn, c_v = einsum_av_relprop(_heads(cam2, num_heads), blk["attn"], v)
+    c_attn, c_v = einsum_av_relprop(_heads(cam2, num_heads), blk["attn"], v, blk.get("z_av"))
     c_attn = c_attn / 2
     c_v = c_v / 2
     attn_cam = c_attn
-    c_q, c_k = einsum_qk_relprop(c_attn, q, k)
+    c_q, c_k = einsum_qk_relprop(c_attn, q, k, blk.get("z_qk"))
     c_q = c_q / 2
     c_k = c_k / 2
     cam_qkv = torch.cat([_unheads(c_q), _unheads(c_k), _unheads(c_v)], dim=-1)
@@ -303,13 +310,13 @@ def bert_layer_relprop(cam: Tensor, lay: dict, num_heads: int, alpha: float = 1.
     c1, c2 = add_relprop(cam, lay["att_add_x0"], lay["att_add_x1"], variant)           # BertSelfOutput :427
     c1 = linear_relprop(c1, lay["att_dense_x"], lay["att_dense_w"], alpha, variant)
     q, k, v = (_heads(lay[n], num_heads) for n in ("q", "k", "v"))
-    cam1, cam_v = matmul_relprop(_heads(c1, num_heads), lay["probs"], v)               # :371
+    cam1, cam_v = matmul_relprop(_heads(c1, num_heads), lay["probs"], v, lay.get("z_av"))   # :371
     cam1 = cam1 / 2
     cam_v = cam_v / 2
     attn_cam = cam1
     if lay.get("ext_mask") is not None:
         cam1, _ = add_relprop(cam1, lay["mask_add_x0"], lay["ext_mask"], variant)      # :386-388
-    cq, ckt = matmul_relprop(cam1, q, k.transpose(-1, -2))                             # :391
+    cq, ckt = matmul_relprop(cam1, q, k.transpose(-1, -2), lay.get("z_qk"))            # :391
     cq = cq / 2
     ckt = ckt / 2
     rq = linear_relprop(_unheads(cq), lay["q_x"], lay["q_w"], alpha, variant)

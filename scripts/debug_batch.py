@@ -91,7 +91,8 @@ def main():
         def s(t):
             return t[i:i + 1] if (torch.is_tensor(t) and t.dim() >= 2 and t.shape[0] == B and t.shape[0] != t.shape[-1]) else t
         out = {k: s(v) for k, v in cache.items() if k != "blocks"}
-        out["blocks"] = [{k: (v if k.endswith("_w") else v[i:i + 1]) for k, v in blk.items()} for blk in cache["blocks"]]
+        out["blocks"] = [{k: (v if (k.endswith("_w") or v is None) else v[i:i + 1]) for k, v in blk.items()}
+                         for blk in cache["blocks"]]
         return out
     for tag, cache in (("batch-cache", sub(cache_b, i)), ("single-cache", caches_s[i])):
         lg = logits_b[i:i + 1].float().cpu()
@@ -99,7 +100,7 @@ def main():
         oh.scatter_(1, lg.argmax(-1, keepdim=True), 1.0)
         for dt in (torch.float32, torch.float64):
             c = {k: (v.to(dt) if torch.is_tensor(v) else v) for k, v in cache.items() if k != "blocks"}
-            c["blocks"] = [{k: v.to(dt) for k, v in blk.items()} for blk in cache["blocks"]]
+            c["blocks"] = [{k: (None if v is None else v.to(dt)) for k, v in blk.items()} for blk in cache["blocks"]]
             ref = O.vit_relprop(oh.to(dt), c, num_heads=12, start_layer=sl)["map"].float()
             print(f"  oracle[{tag},{dt}] vs HIP batch: {float((ref[0] - mb[i].cpu()).abs().max() / ref.abs().max()):.3g}"
                   f"  max|ref| {float(ref.abs().max()):.3g}")

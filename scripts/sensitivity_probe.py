@@ -24,7 +24,7 @@ from transformer_explainability_amd.generators import _attention_gradients  # no
 
 def perturb(cache, eps, gen):
     def p(t):
-        return t * (1 + eps * (2 * torch.rand(t.shape, generator=gen) - 1))
+        return None if t is None else t * (1 + eps * (2 * torch.rand(t.shape, generator=gen) - 1))
     out = {k: (v if k.endswith("_w") else p(v)) for k, v in cache.items() if k != "blocks"}
     out["blocks"] = [{k: (v if k.endswith("_w") else p(v)) for k, v in b.items()} for b in cache["blocks"]]
     return out

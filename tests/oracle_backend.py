@@ -14,7 +14,7 @@ def linear_relprop(R, X, W, alpha=1.0, variant="ours", Y=None, bias=None):
     return O.linear_relprop(R, X, W, alpha=alpha, variant=variant)     # Y / bias: a device-side shortcut only
 
 
-def matmul_relprop_av(R, attn, v, out_scale=1.0, cam_v_out=None, variant="ours"):
+def matmul_relprop_av(R, attn, v, out_scale=1.0, cam_v_out=None, variant="ours", z=None):
     c_attn, c_v = O.einsum_av_relprop(R, attn, v)
     c_attn = c_attn * out_scale
     c_v = c_v * out_scale
@@ -24,7 +24,7 @@ def matmul_relprop_av(R, attn, v, out_scale=1.0, cam_v_out=None, variant="ours")
     return c_attn.contiguous(), c_v
 
 
-def matmul_relprop_qk(R, q, k, out_scale=1.0, cam_q_out=None, cam_k_out=None, variant="ours"):
+def matmul_relprop_qk(R, q, k, out_scale=1.0, cam_q_out=None, cam_k_out=None, variant="ours", z=None):
     c_q, c_k = O.einsum_qk_relprop(R, q, k)
     c_q = c_q * out_scale
     c_k = c_k * out_scale

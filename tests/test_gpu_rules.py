@@ -209,10 +209,12 @@ def test_linear_rows_independent_and_homogeneous():
 
 # ------------------------------------------------------------------------------------------ attention rules
 @pytest.mark.parametrize("simple", [False, True], ids=["tiled", "simple"])
+@pytest.mark.parametrize("with_z", [False, True], ids=["computeZ", "forwardZ"])
 @pytest.mark.parametrize("signed", [False, True], ids=["positive", "mixedsign"])
 @pytest.mark.parametrize("B,H,N,D", [(2, 3, 7, 8), (2, 12, 197, 64), (1, 4, 130, 64), (1, 2, 577, 64), (4, 12, 197, 64),
-                                     (1, 2, 64, 64), (1, 1, 65, 64), (2, 2, 512, 64), (1, 3, 33, 32)])
-def test_attention_rules_fused_qkv_layout(simple, signed, B, H, N, D):
+                                     (1, 2, 64, 64), (1, 1, 65, 64), (2, 2, 512, 64), (1, 3, 33, 32), (1, 2, 1, 64),
+                                     (1, 1, 63, 64), (1, 1, 129, 64)])
+def test_attention_rules_fused_qkv_layout(simple, with_z, signed, B, H, N, D):
     """q/k/v read in place from the fused qkv activation [B,N,3HD]; outputs written in place into the
     'b n (qkv h d)' relevance buffer (strided views).
 
@@ -238,25 +240,33 @@ def test_attention_rules_fused_qkv_layout(simple, signed, B, H, N, D):
     v5d = qkv_d.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
     cam_qkv = torch.full((B, N, 3 * C), float("nan"), device=d)
     slots = cam_qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
-    cam1, cam_v = ops.matmul_relprop_av(Rav.to(d).view(B, N, H, D).permute(0, 2, 1, 3), attn.to(d), v5d[2],
-                                        out_scale=0.5, cam_v_out=slots[2])
-    ops.matmul_relprop_qk(cam1, v5d[0], v5d[1], out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1])
+    # with_z: Z handed over as the forward pass produced it on the device (rocBLAS products), as the model path does
+    attn_d = attn.to(d)
+    z_av = (attn_d @ v5d[2]) if with_z else None
+    z_qk = (v5d[0] @ v5d[1].transpose(-1, -2)) if with_z else None
+    cam1, cam_v = ops.matmul_relprop_av(Rav.to(d).view(B, N, H, D).permute(0, 2, 1, 3), attn_d, v5d[2],
+                                        out_scale=0.5, cam_v_out=slots[2], z=z_av)
+    ops.matmul_relprop_qk(cam1, v5d[0], v5d[1], out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1], z=z_qk)
     assert not torch.isnan(cam_qkv).any()       # every slot of the fused buffer was written
 
     # the QK rule is checked on the relevance the device AV rule produced (its own input), so that each
     # rule is compared on identical inputs
     cam1_c = cam1.cpu()
-    tag = f"({B},{H},{N},{D}){'simple' if simple else 'tiled'}{'+-' if signed else '+'}"
-    ref_attn, ref_v = O.einsum_av_relprop(r_heads, attn, v)
-    ref_q, ref_k = O.einsum_qk_relprop(cam1_c, q, k)
-    if not signed:
+    tag = f"({B},{H},{N},{D}){'simple' if simple else 'tiled'}{'+-' if signed else '+'}{'z' if with_z else ''}"
+    # with_z: the forward products are inputs of the rule (oracle/relprop_oracle.py: matmul_relprop), so the oracle
+    # gets the same Z and even the mixed-sign case is well conditioned (S is then identical up to one division)
+    zc_av = z_av.cpu() if with_z else None
+    zc_qk = z_qk.cpu() if with_z else None
+    ref_attn, ref_v = O.einsum_av_relprop(r_heads, attn, v, zc_av)
+    ref_q, ref_k = O.einsum_qk_relprop(cam1_c, q, k, zc_qk)
+    if not signed or with_z:
         check("av.cam_attn" + tag, cam1, ref_attn * 0.5, 3e-5)
         check("av.cam_v" + tag, slots[2], ref_v * 0.5, 3e-5)
         check("qk.cam_q" + tag, slots[0], ref_q * 0.5, 3e-5)
         check("qk.cam_k" + tag, slots[1], ref_k * 0.5, 3e-5)
     else:
         a64, v64 = O.einsum_av_relprop(r_heads.double(), attn.double(), v.double())
-        q64, k64 = O.einsum_qk_relprop(cam1_c.double(), q.double(), k.double())
+        q64, k64 = O.einsum_qk_relprop(cam1_c.double(), q.double(), k.double())   # (computeZ: Z is part of the rule)
         check_conditioned("av.cam_attn" + tag, cam1, ref_attn * 0.5, a64 * 0.5, 3e-5)
         check_conditioned("av.cam_v" + tag, slots[2], ref_v * 0.5, v64 * 0.5, 3e-5)
         check_conditioned("qk.cam_q" + tag, slots[0], ref_q * 0.5, q64 * 0.5, 3e-5)

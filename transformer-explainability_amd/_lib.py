@@ -39,6 +39,10 @@ SIGNATURES = {
     "te_matmul_relprop_av_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
                                       _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_matmul_relprop_qk_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64]),
+    "te_matmul_relprop_av_fwd_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64,
+                                          _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
+    "te_matmul_relprop_qk_fwd_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
+                                          _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_matmul_relprop_qk_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64,
                                       _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_add_relprop_workspace_bytes": (_SZ, [_I64, _I64]),

@@ -131,12 +131,13 @@ def make_bert_module(L):
             rq = torch.empty((B, N, C), dtype=cam.dtype, device=cam.device)
             rk, rv = torch.empty_like(rq), torch.empty_like(rq)
             as_heads = lambda t: t.view(B, N, H, D).permute(0, 2, 1, 3)          # noqa: E731  (views)
-            cam1, _ = ops.matmul_relprop_av(as_heads(cam), probs, v, out_scale=0.5, cam_v_out=as_heads(rv), variant=var)
+            cam1, _ = ops.matmul_relprop_av(as_heads(cam), probs, v, out_scale=0.5, cam_v_out=as_heads(rv), variant=var,
+                                            z=getattr(self.matmul2, "Y", None))
             self.save_attn_cam(cam1)
             if self.attention_mask is not None:
                 cam1, _ = self.add.relprop(cam1, **kwargs)                          # BERT.py:386-388
             ops.matmul_relprop_qk(cam1, q, kt.transpose(-1, -2), out_scale=0.5, cam_q_out=as_heads(rq),
-                                  cam_k_out=as_heads(rk), variant=var)
+                                  cam_k_out=as_heads(rk), variant=var, z=getattr(self.matmul1, "Y", None))
             rq = self.query.relprop(rq, **kwargs)
             rk = self.key.relprop(rk, **kwargs)
             rv = self.value.relprop(rv, **kwargs)

@@ -18,14 +18,14 @@ namespace te_attn_mfma {
 // implemented in te_attn_mfma.hip; return false if the shape is not supported by the tiled kernels
 bool av_supported(int64_t N, int64_t D);
 int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn,
-              const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, float* cam_attn, float* cam_v,
+              const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* Z, float* cam_attn, float* cam_v,
               int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N, int64_t D,
-              float scale, float* wsS, hipStream_t stream);
+              float scale, float* ws, hipStream_t stream);
 bool qk_supported(int64_t N, int64_t D);
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
-              const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn, float* cam_q, int64_t cq_sb,
+              const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb,
               int64_t cq_sh, int64_t cq_sn, float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
-              int64_t B, int64_t H, int64_t N, int64_t D, float scale, float* wsS, hipStream_t stream);
+              int64_t B, int64_t H, int64_t N, int64_t D, float scale, float* ws, hipStream_t stream);
 }  // namespace te_attn_mfma
 
 namespace {
@@ -48,6 +48,21 @@ __global__ __launch_bounds__(kThreads) void av_s_simple(
   float z = 0.0f;
   for (int64_t j = 0; j < N; ++j) z = fmaf(arow[j], v[vs.at(b, h, j) + d], z);
   S[idx] = te_sd(R[rs.at(b, h, i) + d], z);
+}
+
+// the same with Z = the cached forward product attn v, contiguous [B,H,N,D]
+__global__ __launch_bounds__(kThreads) void av_s_from_z_simple(
+    const float* __restrict__ R, Strided rs, const float* __restrict__ Z, float* __restrict__ S, int64_t B, int64_t H,
+    int64_t N, int64_t D) {
+  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= B * H * N * D) return;
+  const int64_t d = idx % D, i = (idx / D) % N, h = (idx / (D * N)) % H, b = idx / (D * N * H);
+  S[idx] = te_sd(R[rs.at(b, h, i) + d], Z[idx]);
+}
+__global__ __launch_bounds__(kThreads) void qk_s_from_z_simple(const float* __restrict__ R, const float* __restrict__ Z,
+                                                               float* __restrict__ S, int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (idx < n) S[idx] = te_sd(R[idx], Z[idx]);
 }
 
 // cam_attn[b,h,i,j] = attn[b,h,i,j] * (sum_d S[b,h,i,d] v[b,h,j,d]) * scale
@@ -122,10 +137,10 @@ inline bool strides_ok(int64_t sb, int64_t sh, int64_t sn) { return sb >= 0 && s
 
 }  // namespace
 
-// AV workspace: S [B,H,N,D]
+// AV workspace: S [B,H,N,D] + Z [B,H,N,D] (Z only used when the caller has no cached forward product)
 extern "C" size_t te_matmul_relprop_av_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t D) {
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return 0;
-  return te_align_up((size_t)B * H * N * D * sizeof(float), 256);
+  return te_align_up((size_t)2 * B * H * N * D * sizeof(float), 256);
 }
 
 extern "C" int te_matmul_relprop_av_f32(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn,
@@ -134,6 +149,16 @@ extern "C" int te_matmul_relprop_av_f32(const float* R, int64_t r_sb, int64_t r_
                                         int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N,
                                         int64_t D, float out_scale, int variant, void* ws, size_t ws_bytes,
                                         te_stream_t stream_) {
+  return te_matmul_relprop_av_fwd_f32(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, nullptr, cam_attn, cam_v, cv_sb,
+                                      cv_sh, cv_sn, B, H, N, D, out_scale, variant, ws, ws_bytes, stream_);
+}
+
+extern "C" int te_matmul_relprop_av_fwd_f32(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn,
+                                            const float* attn, const float* v, int64_t v_sb, int64_t v_sh,
+                                            int64_t v_sn, const float* Z, float* cam_attn, float* cam_v,
+                                            int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H,
+                                            int64_t N, int64_t D, float out_scale, int variant, void* ws,
+                                            size_t ws_bytes, te_stream_t stream_) {
   if (!R || !attn || !v || !cam_attn || !cam_v || B <= 0 || H <= 0 || N <= 0 || D <= 0)
     return TE_ERR_INVALID_ARG;
   if (!strides_ok(r_sb, r_sh, r_sn) || !strides_ok(v_sb, v_sh, v_sn) || !strides_ok(cv_sb, cv_sh, cv_sn))
@@ -142,7 +167,7 @@ extern "C" int te_matmul_relprop_av_f32(const float* R, int64_t r_sb, int64_t r_
   hipStream_t stream = (hipStream_t)stream_;
   float* S = (float*)ws;
   if (!(variant & TE_IMPL_SIMPLE) && te_attn_mfma::av_supported(N, D)) {
-    int rc = te_attn_mfma::av_launch(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, cam_attn, cam_v, cv_sb,
+    int rc = te_attn_mfma::av_launch(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, cam_attn, cam_v, cv_sb,
                                      cv_sh, cv_sn, B, H, N, D, out_scale, S, stream);
     if (rc != TE_OK) return rc;
     TE_RETURN_IF_LAUNCH_FAILED();
@@ -151,7 +176,8 @@ extern "C" int te_matmul_relprop_av_f32(const float* R, int64_t r_sb, int64_t r_
   const Strided rs{r_sb, r_sh, r_sn}, vs{v_sb, v_sh, v_sn}, cs{cv_sb, cv_sh, cv_sn};
   const int64_t nd = B * H * N * D, nn = B * H * N * N;
   dim3 blk(kThreads);
-  av_s_simple<<<dim3((unsigned)te_ceil_div(nd, kThreads)), blk, 0, stream>>>(R, rs, attn, v, vs, S, B, H, N, D);
+  if (Z) av_s_from_z_simple<<<dim3((unsigned)te_ceil_div(nd, kThreads)), blk, 0, stream>>>(R, rs, Z, S, B, H, N, D);
+  else av_s_simple<<<dim3((unsigned)te_ceil_div(nd, kThreads)), blk, 0, stream>>>(R, rs, attn, v, vs, S, B, H, N, D);
   av_cam_attn_simple<<<dim3((unsigned)te_ceil_div(nn, kThreads)), blk, 0, stream>>>(S, attn, v, vs, cam_attn, B,
                                                                                    H, N, D, out_scale);
   av_cam_v_simple<<<dim3((unsigned)te_ceil_div(nd, kThreads)), blk, 0, stream>>>(S, attn, v, vs, cam_v, cs, B, H,
@@ -160,10 +186,10 @@ extern "C" int te_matmul_relprop_av_f32(const float* R, int64_t r_sb, int64_t r_
   return TE_OK;
 }
 
-// QK workspace: S [B,H,N,N]
+// QK workspace: S [B,H,N,N] + Z [B,H,N,N] (Z only used when the caller has no cached forward product)
 extern "C" size_t te_matmul_relprop_qk_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t D) {
   if (B <= 0 || H <= 0 || N <= 0 || D <= 0) return 0;
-  return te_align_up((size_t)B * H * N * N * sizeof(float), 256);
+  return te_align_up((size_t)2 * B * H * N * N * sizeof(float), 256);
 }
 
 extern "C" int te_matmul_relprop_qk_f32(const float* R_nn, const float* q, int64_t q_sb, int64_t q_sh,
@@ -172,6 +198,18 @@ extern "C" int te_matmul_relprop_qk_f32(const float* R_nn, const float* q, int64
                                         int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H,
                                         int64_t N, int64_t D, float out_scale, int variant, void* ws,
                                         size_t ws_bytes, te_stream_t stream_) {
+  return te_matmul_relprop_qk_fwd_f32(R_nn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, nullptr, cam_q, cq_sb, cq_sh,
+                                      cq_sn, cam_k, ck_sb, ck_sh, ck_sn, B, H, N, D, out_scale, variant, ws, ws_bytes,
+                                      stream_);
+}
+
+extern "C" int te_matmul_relprop_qk_fwd_f32(const float* R_nn, const float* q, int64_t q_sb, int64_t q_sh,
+                                            int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh,
+                                            int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb,
+                                            int64_t cq_sh, int64_t cq_sn, float* cam_k, int64_t ck_sb,
+                                            int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N,
+                                            int64_t D, float out_scale, int variant, void* ws, size_t ws_bytes,
+                                            te_stream_t stream_) {
   if (!R_nn || !q || !k || !cam_q || !cam_k || B <= 0 || H <= 0 || N <= 0 || D <= 0) return TE_ERR_INVALID_ARG;
   if (!strides_ok(q_sb, q_sh, q_sn) || !strides_ok(k_sb, k_sh, k_sn) || !strides_ok(cq_sb, cq_sh, cq_sn) ||
       !strides_ok(ck_sb, ck_sh, ck_sn))
@@ -180,7 +218,7 @@ extern "C" int te_matmul_relprop_qk_f32(const float* R_nn, const float* q, int64
   hipStream_t stream = (hipStream_t)stream_;
   float* S = (float*)ws;
   if (!(variant & TE_IMPL_SIMPLE) && te_attn_mfma::qk_supported(N, D)) {
-    int rc = te_attn_mfma::qk_launch(R_nn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, cam_q, cq_sb, cq_sh, cq_sn,
+    int rc = te_attn_mfma::qk_launch(R_nn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn,
                                      cam_k, ck_sb, ck_sh, ck_sn, B, H, N, D, out_scale, S, stream);
     if (rc != TE_OK) return rc;
     TE_RETURN_IF_LAUNCH_FAILED();
@@ -189,7 +227,8 @@ extern "C" int te_matmul_relprop_qk_f32(const float* R_nn, const float* q, int64
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
   const int64_t nd = B * H * N * D, nn = B * H * N * N;
   dim3 blk(kThreads);
-  qk_s_simple<<<dim3((unsigned)te_ceil_div(nn, kThreads)), blk, 0, stream>>>(R_nn, q, qs, k, ks, S, B, H, N, D);
+  if (Z) qk_s_from_z_simple<<<dim3((unsigned)te_ceil_div(nn, kThreads)), blk, 0, stream>>>(R_nn, Z, S, nn);
+  else qk_s_simple<<<dim3((unsigned)te_ceil_div(nn, kThreads)), blk, 0, stream>>>(R_nn, q, qs, k, ks, S, B, H, N, D);
   qk_cam_q_simple<<<dim3((unsigned)te_ceil_div(nd, kThreads)), blk, 0, stream>>>(S, q, qs, k, ks, cam_q, cqs, B, H,
                                                                                 N, D, out_scale);
   qk_cam_k_simple<<<dim3((unsigned)te_ceil_div(nd, kThreads)), blk, 0, stream>>>(S, q, qs, k, ks, cam_k, cks, B, H,

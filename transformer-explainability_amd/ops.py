@@ -76,6 +76,9 @@ class _on_device:
 # Linear.relprop obtains Z from the forward output when the caller supplies it (te_linear_relprop_fwd_f32): one GEMM
 # less per rule.  Tests flip this to run the two-GEMM Z-pass on the same inputs.
 USE_FORWARD_OUTPUT = True
+# The attention rules take Z = the forward product of the very einsum / MatMul whose rule is evaluated (what the
+# reference's autograd re-evaluation reproduces bit for bit) instead of recomputing it in another summation order.
+USE_FORWARD_PRODUCTS = True
 
 
 def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant="ours",
@@ -138,12 +141,22 @@ def _bhnd(t: Tensor) -> Tuple[Tensor, int, int, int]:
     return t, sb, sh, sn
 
 
+def _cached_z(z: Optional[Tensor], shape) -> Optional[Tensor]:
+    """The forward product the einsum / MatMul module cached as self.Y, if it has the expected shape."""
+    if z is None or not USE_FORWARD_PRODUCTS or tuple(z.shape) != tuple(shape):
+        return None
+    return _c(z.detach())
+
+
 def matmul_relprop_av(R: Tensor, attn: Tensor, v: Tensor, out_scale: float = 1.0,
-                      cam_v_out: Optional[Tensor] = None, variant="ours") -> Tuple[Tensor, Tensor]:
+                      cam_v_out: Optional[Tensor] = None, variant="ours", z: Optional[Tensor] = None
+                      ) -> Tuple[Tensor, Tensor]:
     """AV rule.  R, v: [B,H,N,D] (any strides with contiguous D); attn [B,H,N,N].
     Returns (cam_attn [B,H,N,N], cam_v [B,H,N,D]); cam_v is written into `cam_v_out` if given (a
-    [B,H,N,D] view, e.g. a slice of the 'b n (qkv h d)' relevance buffer)."""
+    [B,H,N,D] view, e.g. a slice of the 'b n (qkv h d)' relevance buffer).  z (optional) = attn @ v as the
+    forward pass computed it (self.Y of the product module)."""
     B, H, N, D = v.shape
+    zc = _cached_z(z, (B, H, N, D))
     R, r_sb, r_sh, r_sn = _bhnd(R)
     v, v_sb, v_sh, v_sn = _bhnd(v)
     attn = _c(attn)
@@ -154,18 +167,20 @@ def matmul_relprop_av(R: Tensor, attn: Tensor, v: Tensor, out_scale: float = 1.0
     cv_sb, cv_sh, cv_sn, _ = cam_v.stride()
     with _on_device(attn) as lib:
         ws = _ws(lib.te_matmul_relprop_av_workspace_bytes(B, H, N, D), attn)
-        _lib.check(lib.te_matmul_relprop_av_f32(
-            _ptr(R), r_sb, r_sh, r_sn, _ptr(attn), _ptr(v), v_sb, v_sh, v_sn, _ptr(cam_attn),
+        _lib.check(lib.te_matmul_relprop_av_fwd_f32(
+            _ptr(R), r_sb, r_sh, r_sn, _ptr(attn), _ptr(v), v_sb, v_sh, v_sn, _ptr(zc), _ptr(cam_attn),
             _ptr(cam_v), cv_sb, cv_sh, cv_sn, B, H, N, D, float(out_scale), _variant(variant),
-            _ptr(ws), ws.numel(), _stream(attn)), "te_matmul_relprop_av_f32")
+            _ptr(ws), ws.numel(), _stream(attn)), "te_matmul_relprop_av_fwd_f32")
     return cam_attn, cam_v
 
 
 def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
                       cam_q_out: Optional[Tensor] = None, cam_k_out: Optional[Tensor] = None,
-                      variant="ours") -> Tuple[Tensor, Tensor]:
-    """QK rule.  R [B,H,N,N]; q, k [B,H,N,D] -> (cam_q, cam_k) [B,H,N,D]."""
+                      variant="ours", z: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """QK rule.  R [B,H,N,N]; q, k [B,H,N,D] -> (cam_q, cam_k) [B,H,N,D].  z (optional) = the UNSCALED q @ k^T as
+    the forward pass computed it (self.Y of the product module)."""
     B, H, N, D = q.shape
+    zc = _cached_z(z, (B, H, N, N))
     q, q_sb, q_sh, q_sn = _bhnd(q)
     k, k_sb, k_sh, k_sn = _bhnd(k)
     R = _c(R)
@@ -177,11 +192,11 @@ def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
     cq, ck = cam_q.stride(), cam_k.stride()
     with _on_device(R) as lib:
         ws = _ws(lib.te_matmul_relprop_qk_workspace_bytes(B, H, N, D), R)
-        _lib.check(lib.te_matmul_relprop_qk_f32(
-            _ptr(R), _ptr(q), q_sb, q_sh, q_sn, _ptr(k), k_sb, k_sh, k_sn,
+        _lib.check(lib.te_matmul_relprop_qk_fwd_f32(
+            _ptr(R), _ptr(q), q_sb, q_sh, q_sn, _ptr(k), k_sb, k_sh, k_sn, _ptr(zc),
             _ptr(cam_q), cq[0], cq[1], cq[2], _ptr(cam_k), ck[0], ck[1], ck[2],
             B, H, N, D, float(out_scale), _variant(variant), _ptr(ws), ws.numel(), _stream(R)),
-            "te_matmul_relprop_qk_f32")
+            "te_matmul_relprop_qk_fwd_f32")
     return cam_q, cam_k
 
 

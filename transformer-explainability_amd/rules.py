@@ -43,6 +43,12 @@ def forward_hook(self, input, output):
     self.Y = output
 
 
+def _cached_y(module):
+    """The forward output forward_hook stored (the product whose rule is being evaluated), or None."""
+    y = getattr(module, "Y", None)
+    return y if torch.is_tensor(y) else None
+
+
 class RelProp(nn.Module):
     variant = "ours"
 
@@ -123,10 +129,10 @@ class einsum(RelProp):
     def relprop(self, R, alpha):
         eq = self.equation.replace(" ", "")
         if eq == 'bhij,bhjd->bhid':
-            cam_attn, cam_v = ops.matmul_relprop_av(R, self.X[0], self.X[1], variant=self.variant)
+            cam_attn, cam_v = ops.matmul_relprop_av(R, self.X[0], self.X[1], variant=self.variant, z=_cached_y(self))
             return [cam_attn, cam_v]
         if eq == 'bhid,bhjd->bhij':
-            cam_q, cam_k = ops.matmul_relprop_qk(R, self.X[0], self.X[1], variant=self.variant)
+            cam_q, cam_k = ops.matmul_relprop_qk(R, self.X[0], self.X[1], variant=self.variant, z=_cached_y(self))
             return [cam_q, cam_k]
         raise NotImplementedError(f"einsum.relprop: equation {self.equation!r} is not on the accelerated path")
 
@@ -143,14 +149,14 @@ class MatMul(RelProp):
             raise NotImplementedError("MatMul.relprop: only [B,H,.,.] attention products are accelerated")
         if x1.stride(-1) != 1 and x1.stride(-2) == 1:          # [Q, K^T] with K^T a transposed view
             k = x1.transpose(-1, -2)
-            cam_q, cam_k = ops.matmul_relprop_qk(R, x0, k, variant=self.variant)
+            cam_q, cam_k = ops.matmul_relprop_qk(R, x0, k, variant=self.variant, z=_cached_y(self))
             return [cam_q, cam_k.transpose(-1, -2)]
         if x0.shape[-1] == x0.shape[-2] == x1.shape[-2]:       # [probs, V]
-            cam_attn, cam_v = ops.matmul_relprop_av(R, x0, x1, variant=self.variant)
+            cam_attn, cam_v = ops.matmul_relprop_av(R, x0, x1, variant=self.variant, z=_cached_y(self))
             return [cam_attn, cam_v]
         if x0.shape[-1] == x1.shape[-2]:                        # [Q, K^T] materialised contiguously
             k = x1.transpose(-1, -2).contiguous()
-            cam_q, cam_k = ops.matmul_relprop_qk(R, x0, k, variant=self.variant)
+            cam_q, cam_k = ops.matmul_relprop_qk(R, x0, k, variant=self.variant, z=_cached_y(self))
             return [cam_q, cam_k.transpose(-1, -2)]
         raise NotImplementedError("MatMul.relprop: operand shapes are not an attention product")
 

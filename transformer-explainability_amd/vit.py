@@ -112,10 +112,12 @@ def make_vit_module(L):
             cam_qkv = torch.empty((B, N, 3 * C), dtype=cam.dtype, device=cam.device)
             slots = cam_qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)          # [3][B,H,N,D] views
             var = self.matmul2.variant
-            cam1, cam_v = ops.matmul_relprop_av(r_heads, attn, v, out_scale=0.5, cam_v_out=slots[2], variant=var)
+            cam1, cam_v = ops.matmul_relprop_av(r_heads, attn, v, out_scale=0.5, cam_v_out=slots[2], variant=var,
+                                                z=getattr(self.matmul2, "Y", None))
             self.save_v_cam(cam_v)
             self.save_attn_cam(cam1)
-            ops.matmul_relprop_qk(cam1, q, k, out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1], variant=var)
+            ops.matmul_relprop_qk(cam1, q, k, out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1], variant=var,
+                                  z=getattr(self.matmul1, "Y", None))
             return self.qkv.relprop(cam_qkv, **kwargs)
 
     class Block(nn.Module):
