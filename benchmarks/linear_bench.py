@@ -83,7 +83,9 @@ def main():
         Y = torch.nn.functional.linear(X, W, bias)
         legs = [("zpass", lib.te_linear_zpass_f32, (R, X, W, S), 2.0 * T * (2 * in_f) * out_f),
                 ("cpass", lib.te_linear_cpass_f32, (S, X, W, out), 2.0 * T * (2 * in_f) * out_f)]
-        if not args.lib:
+        if not args.lib or "prev" in args.lib:
+            lib.te_linear_zpass_fwd_f32.restype = ctypes.c_int
+            lib.te_linear_zpass_fwd_f32.argtypes = _lib.SIGNATURES["te_linear_zpass_fwd_f32"][1]
             legs.insert(1, ("zfwd", lib.te_linear_zpass_fwd_f32, (R, X, W, Y, bias, S), 2.0 * T * in_f * out_f))
         for kname, fn, a, flops in legs:
             ptrs = [t.data_ptr() for t in a]

@@ -1,0 +1,16 @@
+#!/bin/bash
+# One GPU trip: parity tests, smoke, bench line, rocprofv3 kernel stats of the same command.
+#   gpurun --timeout 1500 -- 'bash scripts/gpu_check.sh'      (logs land in gpurun_out/)
+mkdir -p gpurun_out; rm -f gpurun_out/parity_report.jsonl; rm -rf gpurun_out/prof; export TMPDIR=/tmp
+( timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=5 2>&1 | tail -25 ) > gpurun_out/tests_full.log
+( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5 ) > gpurun_out/smoke.log
+( timeout 300 python bench.py > gpurun_out/bench_b64.json 2> gpurun_out/bench_b64.err )
+( cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d "$OLDPWD/gpurun_out/prof" -o bench -- \
+    python "$OLDPWD/bench.py" --cpu-baseline off > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof_bench.err" )
+rm -f gpurun_out/prof/*agent_info* gpurun_out/prof/*kernel_trace*
+( timeout 200 python benchmarks/linear_bench.py 2>&1 | grep -v "^{" | tail -20 ) > gpurun_out/linear_microbench.log
+echo "=== tests ==="; cat gpurun_out/tests_full.log
+echo "=== smoke ==="; cat gpurun_out/smoke.log
+echo "=== bench ==="; cat gpurun_out/bench_b64.json; tail -6 gpurun_out/bench_b64.err
+echo "=== rocprof top kernels ==="; head -8 gpurun_out/prof/bench_kernel_stats.csv | cut -d, -f1-4
+echo "=== linear microbench ==="; cat gpurun_out/linear_microbench.log

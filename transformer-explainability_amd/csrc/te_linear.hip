@@ -40,14 +40,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "te_common.h"
+#include <type_traits>
 
-// Measurement builds only (benchmarks/build_ablations.sh): TE_ABLATION = 1 main loop without global loads / LDS
-// stores / barriers (the first tile is reused), 2 = 1 + operands fed to the MFMAs without the +/- split,
-// 3 = full loop, epilogue without safe_divide.  The product library is always built with 0.
-#ifndef TE_ABLATION
-#define TE_ABLATION 0
-#endif
+#include "te_common.h"
 
 namespace {
 
@@ -55,7 +50,6 @@ constexpr int BK = 32;
 constexpr int LDT = BK;           // K-contiguous tiles are [rows][32] floats = 128-B rows, XOR-swizzled (swz())
 constexpr int kThreads = 256;
 constexpr int kCUs = 256;
-constexpr size_t kLdsPerCU = 160 * 1024;
 
 // 16-B chunk c (0..7) of row r lives at chunk c ^ ((r >> 1) & 7).  With 128-B rows two consecutive rows span
 // the 256-B bank row, so a ds_read_b128 lane group (16 lanes = 16 different rows, 8 even + 8 odd, same logical
@@ -147,11 +141,37 @@ __device__ __forceinline__ TileCoord tile_coord(int v, int ntiles, int nbn) {
   return {(int64_t)(tile / nbn) * BM, (int64_t)(tile % nbn) * BN};
 }
 
-// Both kernels walk the tiles v = blockIdx.x, + gridDim.x, ...  With the default launch (grid = number of tiles)
-// that is one tile per block; with a persistent grid (TE_LINEAR_PERSIST=1: blocks-per-CU x 256, a multiple of 8 so
-// a block keeps its XCD) the K-steps of a block's tiles form one software pipeline in which the first operands of
-// the next tile are fetched under the last K-step of the current one.  Measured neutral on MI355X, so
-// the simpler launch is the default.
+// Unguarded staging loads for interior tiles (every row / column / k of the tile exists): no predication, no
+// branches -- the guarded forms above cost ~70 instructions and 6 taken-or-not branches per K-step.
+template <int ROWS>
+__device__ __forceinline__ void load_rows_tile_fast(const float* __restrict__ M, int64_t K, int64_t row0, int64_t k0,
+                                                    f32x4 (&reg)[ROWS / 32]) {
+  const float* p = M + (row0 + (threadIdx.x >> 3)) * K + k0 + ((threadIdx.x & 7) << 2);
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) reg[i] = *reinterpret_cast<const f32x4*>(p + (int64_t)i * 32 * K);
+}
+template <int BN>
+__device__ __forceinline__ void load_kn_tile_fast(const float* __restrict__ M, int64_t Nn, int64_t k0, int64_t n0,
+                                                  f32x4 (&reg)[BN / 32]) {
+  constexpr int RPI = kThreads / (BN / 4);   // k rows covered per iteration
+  const float* p = M + (k0 + threadIdx.x / (BN / 4)) * Nn + n0 + ((threadIdx.x % (BN / 4)) << 2);
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) reg[i] = *reinterpret_cast<const f32x4*>(p + (int64_t)i * RPI * Nn);
+}
+
+// K-loop schedule shared by both kernels (one K-step = 4 k-groups of 8):
+//
+//     k-group 0 : MFMAs on fragments read during the PREVIOUS step's last group   | reads of group 1
+//                 global loads of the next K-step's tiles are issued
+//     k-group 1 : MFMAs                                                            | reads of group 2
+//     k-group 2 : MFMAs                                                            | reads of group 3
+//                 next tiles: registers -> the other LDS stage ; __syncthreads()
+//     k-group 3 : MFMAs                                                            | reads of group 0 of the NEXT stage
+//
+// so the one barrier of a K-step and the LDS latency of the first fragments sit under a k-group of MFMAs (>= 512
+// MFMA-pipe cycles) instead of between two K-steps, and the staging instructions are spread over the step.  After
+// the barrier nobody reads the current stage any more (group 3 is already in registers), which is what lets the
+// next step overwrite it.
 
 // ------------------------------------------------------------------------------------------------
 // K1: S = sd(R, X+ W+^T + X- W-^T)        SWAP exchanges W+ / W- (inhibitor term, beta != 0)
@@ -183,14 +203,16 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
   constexpr int WM = BM / 2, WN = BN / 2;     // rows / columns per wave
   constexpr int A_SZ = BM * LDT;
   constexpr int STAGE = (BM + BN) * LDT;      // floats per pipeline stage: [A tile | B tile]
+  static_assert(!(FWD && SWAP), "the forward-output Z-pass has no inhibitor form");
 
-  const int G = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, kh = lane >> 5;
+  const TileCoord tc = tile_coord<BM, BN>(blockIdx.x, ntiles, nbn);
+  const int nk = (int)((K + BK - 1) / BK);
+  const bool interior = (tc.row0 + BM <= T) && (tc.col0 + BN <= Nn) && (K % BK == 0);   // block-uniform
 
   constexpr int NACC = LRP ? 2 : 1;
-  static_assert(!(FWD && SWAP), "the forward-output Z-pass has no inhibitor form");
   f32x16 acc[NACC][MI][NI];
 #pragma unroll
   for (int s = 0; s < NACC; ++s)
@@ -201,140 +223,129 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][mi][ni][e] = 0.0f;
 
-  f32x4 ra[BM / 32], rb[BN / 32];
-  const int nk = (int)((K + BK - 1) / BK);
-  int v = blockIdx.x;
-  TileCoord tc = tile_coord<BM, BN>(v, ntiles, nbn);
-  load_rows_tile<BM>(X, T, K, tc.row0, 0, ra);
-  load_rows_tile<BN>(W, Nn, K, tc.col0, 0, rb);
-  store_rows_tile<BM>(smem, ra);
-  store_rows_tile<BN>(smem + A_SZ, rb);
-  __syncthreads();
-
-  // one K-step of MFMAs on the LDS stage `cur`
-  auto mma = [&](int cur) __attribute__((always_inline)) {
-    const float* a_tile = smem + cur * STAGE;
-    const float* b_tile = smem + cur * STAGE + A_SZ;
+  struct Frag {
+    f32x4 a[MI], b[NI];
+  };
+  auto read_frag = [&](Frag& f, int stage, int kg) __attribute__((always_inline)) {
+    const float* a_tile = smem + stage * STAGE;
+    const float* b_tile = a_tile + A_SZ;
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      f32x4 a[MI], b[NI];
+    for (int mi = 0; mi < MI; ++mi)
+      f.a[mi] = *reinterpret_cast<const f32x4*>(a_tile + swz(wm * WM + mi * 32 + lr, kg * 2 + kh));
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        a[mi] = *reinterpret_cast<const f32x4*>(a_tile + swz(wm * WM + mi * 32 + lr, kg * 2 + kh));
+    for (int ni = 0; ni < NI; ++ni)
+      f.b[ni] = *reinterpret_cast<const f32x4*>(b_tile + swz(wn * WN + ni * 32 + lr, kg * 2 + kh));
+  };
+  auto mma_group = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        b[ni] = *reinterpret_cast<const f32x4*>(b_tile + swz(wn * WN + ni * 32 + lr, kg * 2 + kh));
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (FWD) {
+        float aa[MI], ab[NI];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (FWD) {
-          float aa[MI], ab[NI];
+        for (int mi = 0; mi < MI; ++mi) aa[mi] = te_abs(f.a[mi][j]);
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) aa[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_abs(a[mi][j]);
+        for (int ni = 0; ni < NI; ++ni) ab[ni] = te_abs(f.b[ni][j]);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) ab[ni] = (TE_ABLATION == 2) ? b[ni][j] : te_abs(b[ni][j]);
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+          for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(aa[mi], ab[ni], acc[0][mi][ni]);
+      } else {
+        float ap[MI], an[MI], bp[NI], bn[NI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(aa[mi], ab[ni], acc[0][mi][ni]);
-        } else {
-          float ap[MI], an[MI], bp[NI], bn[NI];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            ap[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_pos(a[mi][j]);
-            an[mi] = (TE_ABLATION == 2) ? a[mi][j] : te_neg(a[mi][j]);
-          }
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const float p = (TE_ABLATION == 2) ? b[ni][j] : te_pos(b[ni][j]);
-            const float n = (TE_ABLATION == 2) ? b[ni][j] : te_neg(b[ni][j]);
-            bp[ni] = SWAP ? n : p;   // partner of X+
-            bn[ni] = SWAP ? p : n;   // partner of X-
-          }
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(ap[mi], bp[ni], acc[0][mi][ni]);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[NACC - 1][mi][ni] = TE_MFMA(an[mi], bn[ni], acc[NACC - 1][mi][ni]);
+        for (int mi = 0; mi < MI; ++mi) {
+          ap[mi] = te_pos(f.a[mi][j]);
+          an[mi] = te_neg(f.a[mi][j]);
         }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const float p = te_pos(f.b[ni][j]), n = te_neg(f.b[ni][j]);
+          bp[ni] = SWAP ? n : p;   // partner of X+
+          bn[ni] = SWAP ? p : n;   // partner of X-
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(ap[mi], bp[ni], acc[0][mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[NACC - 1][mi][ni] = TE_MFMA(an[mi], bn[ni], acc[NACC - 1][mi][ni]);
       }
     }
   };
-  constexpr bool kStaged = (TE_ABLATION != 1 && TE_ABLATION != 2);
 
-  int cur = 0;
-  for (; v < ntiles; v += G) {
-    const bool has_next = (v + G) < ntiles;
-    // ---- K-steps 0 .. nk-2: operands of step kt+1 in flight under the MFMAs of step kt
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-      if (kStaged) {
-        load_rows_tile<BM>(X, T, K, tc.row0, (int64_t)(kt + 1) * BK, ra);
-        load_rows_tile<BN>(W, Nn, K, tc.col0, (int64_t)(kt + 1) * BK, rb);
+  auto k_loop = [&](auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    f32x4 ra[BM / 32], rb[BN / 32];
+    auto load_next = [&](int kt) __attribute__((always_inline)) {
+      if constexpr (FAST) {
+        load_rows_tile_fast<BM>(X, K, tc.row0, (int64_t)kt * BK, ra);
+        load_rows_tile_fast<BN>(W, K, tc.col0, (int64_t)kt * BK, rb);
+      } else {
+        load_rows_tile<BM>(X, T, K, tc.row0, (int64_t)kt * BK, ra);
+        load_rows_tile<BN>(W, Nn, K, tc.col0, (int64_t)kt * BK, rb);
       }
-      mma(kStaged ? cur : 0);
-      if (!kStaged) {
-        asm volatile("" ::: "memory");   // keep the LDS fragment reads inside the loop
-        continue;
-      }
-      store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
-      store_rows_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
-      __syncthreads();
-      cur ^= 1;
-    }
-    // ---- last K-step (persistent grids: the FIRST operands of this block's next tile in flight under it)
-    TileCoord tn = tc;
-    if (has_next) {
-      tn = tile_coord<BM, BN>(v + G, ntiles, nbn);
-      if (kStaged) {
-        load_rows_tile<BM>(X, T, K, tn.row0, 0, ra);
-        load_rows_tile<BN>(W, Nn, K, tn.col0, 0, rb);
-      }
-    }
-    mma(kStaged ? cur : 0);
-
-    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
-    // (An "interior tile" fast path with scalar-base addressing was tried: it doubled the live address registers
-    // and cost a co-resident block per CU -- not kept.)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          if (gr < T && gc < Nn) {
-            const float r = R[gr * Nn + gc];
-            if constexpr (LRP) {
-              S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
-              S2[gr * Nn + gc] = te_sd(r, acc[1][mi][ni][e]);
-            } else if constexpr (FWD) {
-              const float a_abs = acc[0][mi][ni][e];                          // |X| |W|^T  >= 0
-              const float lin = Y[gr * Nn + gc] - (bias ? bias[gc] : 0.0f);   // X W^T
-              float z = 0.5f * (lin + a_abs);
-              if (!(z > kCancelTol * a_abs)) z = exact_z(X + gr * K, W + gc * K, K);   // cancellation / all-zero row
-              S1[gr * Nn + gc] = te_sd(r, z);
-            } else {
-              S1[gr * Nn + gc] = (TE_ABLATION == 3) ? r * acc[0][mi][ni][e] : te_sd(r, acc[0][mi][ni][e]);
-            }
-          }
-#pragma unroll
-          for (int s = 0; s < NACC; ++s) acc[s][mi][ni][e] = 0.0f;
-        }
-      }
-    if (kStaged) {
-      if (has_next) {
+    };
+    load_next(0);
+    store_rows_tile<BM>(smem, ra);
+    store_rows_tile<BN>(smem + A_SZ, rb);
+    __syncthreads();
+    Frag f0, f1;
+    read_frag(f0, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      read_frag(f1, cur, 1);
+      mma_group(f0);
+      if (more) load_next(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frag(f0, cur, 2);
+      mma_group(f1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frag(f1, cur, 3);
+      mma_group(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
         store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
         store_rows_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
+        __syncthreads();
+        read_frag(f0, cur ^ 1, 0);
       }
-      __syncthreads();
+      mma_group(f1);
+      __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
     }
-    tc = tn;
-  }
+  };
+  if (interior) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+
+  // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (gr < T && gc < Nn) {
+          const float r = R[gr * Nn + gc];
+          if constexpr (LRP) {
+            S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
+            S2[gr * Nn + gc] = te_sd(r, acc[1][mi][ni][e]);
+          } else if constexpr (FWD) {
+            const float a_abs = acc[0][mi][ni][e];                          // |X| |W|^T  >= 0
+            const float lin = Y[gr * Nn + gc] - (bias ? bias[gc] : 0.0f);   // X W^T
+            float z = 0.5f * (lin + a_abs);
+            if (!(z > kCancelTol * a_abs)) z = exact_z(X + gr * K, W + gc * K, K);   // cancellation / all-zero row
+            S1[gr * Nn + gc] = te_sd(r, z);
+          } else {
+            S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
+          }
+        }
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,10 +363,12 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
   constexpr int A_SZ = BM * LDT, B_SZ = BK * BN;
   constexpr int STAGE = A_SZ + B_SZ;   // floats per pipeline stage: [A tile | B tile]
 
-  const int G = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, kh = lane >> 5;
+  const TileCoord tc = tile_coord<BM, BN>(blockIdx.x, ntiles, nbn);
+  const int nk = (int)((K + BK - 1) / BK);
+  const bool interior = (tc.row0 + BM <= T) && (tc.col0 + BN <= Nn) && (K % BK == 0);   // block-uniform
 
   constexpr int NACC = (MODE == 0) ? 2 : 1;
   f32x16 acc[NACC][MI][NI];
@@ -368,119 +381,114 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][mi][ni][e] = 0.0f;
 
-  f32x4 ra[BM / 32], rb[BN / 32];
-  const int nk = (int)((K + BK - 1) / BK);
-  int v = blockIdx.x;
-  TileCoord tc = tile_coord<BM, BN>(v, ntiles, nbn);
-  load_rows_tile<BM>(S, T, K, tc.row0, 0, ra);
-  load_kn_tile<BN>(W, K, Nn, 0, tc.col0, rb);
-  store_rows_tile<BM>(smem, ra);
-  store_kn_tile<BN>(smem + A_SZ, rb);
-  __syncthreads();
-
-  auto mma = [&](int cur) __attribute__((always_inline)) {
-    const float* a_tile = smem + cur * STAGE;
-    const float* b_base = smem + cur * STAGE + A_SZ + (kh * 4) * BN + wn * WN + lr;
+  struct Frag {
+    f32x4 a[MI];
+    float b[4][NI];   // W[k][n] for the 4 k of the group
+  };
+  auto read_frag = [&](Frag& f, int stage, int kg) __attribute__((always_inline)) {
+    const float* a_tile = smem + stage * STAGE;
+    const float* b_base = a_tile + A_SZ + (kh * 4) * BN + wn * WN + lr;
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      f32x4 a[MI];
+    for (int mi = 0; mi < MI; ++mi)
+      f.a[mi] = *reinterpret_cast<const f32x4*>(a_tile + swz(wm * WM + mi * 32 + lr, kg * 2 + kh));
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        a[mi] = *reinterpret_cast<const f32x4*>(a_tile + swz(wm * WM + mi * 32 + lr, kg * 2 + kh));
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float bp[NI], bn[NI];
+      for (int ni = 0; ni < NI; ++ni) f.b[j][ni] = b_base[(kg * 8 + j) * BN + ni * 32];
+  };
+  auto mma_group = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const float w = b_base[(kg * 8 + j) * BN + ni * 32];
-          const float p = (TE_ABLATION == 2) ? w : te_pos(w), n = (TE_ABLATION == 2) ? w : te_neg(w);
-          bp[ni] = SWAP ? n : p;
-          bn[ni] = SWAP ? p : n;
-        }
-        if constexpr (MODE == 0 || MODE == 1) {
+    for (int j = 0; j < 4; ++j) {
+      float bp[NI], bn[NI];
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+      for (int ni = 0; ni < NI; ++ni) {
+        const float p = te_pos(f.b[j][ni]), n = te_neg(f.b[j][ni]);
+        bp[ni] = SWAP ? n : p;
+        bn[ni] = SWAP ? p : n;
+      }
+      if constexpr (MODE == 0 || MODE == 1) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(a[mi][j], bp[ni], acc[0][mi][ni]);
-        }
-        if constexpr (MODE == 0 || MODE == 2) {
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
+          for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(f.a[mi][j], bp[ni], acc[0][mi][ni]);
+      }
+      if constexpr (MODE == 0 || MODE == 2) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[NACC - 1][mi][ni] = TE_MFMA(a[mi][j], bn[ni], acc[NACC - 1][mi][ni]);
-        }
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[NACC - 1][mi][ni] = TE_MFMA(f.a[mi][j], bn[ni], acc[NACC - 1][mi][ni]);
       }
     }
   };
-  constexpr bool kStaged = (TE_ABLATION != 1 && TE_ABLATION != 2);
 
-  int cur = 0;
-  for (; v < ntiles; v += G) {
-    const bool has_next = (v + G) < ntiles;
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-      if (kStaged) {
-        load_rows_tile<BM>(S, T, K, tc.row0, (int64_t)(kt + 1) * BK, ra);
-        load_kn_tile<BN>(W, K, Nn, (int64_t)(kt + 1) * BK, tc.col0, rb);
+  auto k_loop = [&](auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    f32x4 ra[BM / 32], rb[BN / 32];
+    auto load_next = [&](int kt) __attribute__((always_inline)) {
+      if constexpr (FAST) {
+        load_rows_tile_fast<BM>(S, K, tc.row0, (int64_t)kt * BK, ra);
+        load_kn_tile_fast<BN>(W, Nn, (int64_t)kt * BK, tc.col0, rb);
+      } else {
+        load_rows_tile<BM>(S, T, K, tc.row0, (int64_t)kt * BK, ra);
+        load_kn_tile<BN>(W, K, Nn, (int64_t)kt * BK, tc.col0, rb);
       }
-      mma(kStaged ? cur : 0);
-      if (!kStaged) {
-        asm volatile("" ::: "memory");   // keep the LDS fragment reads inside the loop
-        continue;
-      }
-      store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
-      store_kn_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
-      __syncthreads();
-      cur ^= 1;
-    }
-    TileCoord tn = tc;
-    if (has_next) {
-      tn = tile_coord<BM, BN>(v + G, ntiles, nbn);
-      if (kStaged) {
-        load_rows_tile<BM>(S, T, K, tn.row0, 0, ra);
-        load_kn_tile<BN>(W, K, Nn, 0, tn.col0, rb);
-      }
-    }
-    mma(kStaged ? cur : 0);
-
-    auto finish = [&](float x, float old, int mi, int ni, int e) __attribute__((always_inline)) -> float {
-      const float xp = fmaxf(x, 0.0f), xn = fminf(x, 0.0f);
-      float val;
-      if constexpr (MODE == 0) val = xp * acc[0][mi][ni][e] + xn * acc[1][mi][ni][e];
-      else if constexpr (MODE == 1) val = xp * acc[0][mi][ni][e];
-      else val = xn * acc[0][mi][ni][e];
-      val = scale * val;
-      if constexpr (ACCUM) val = old - val;          // alpha*act - beta*inh
-      else if constexpr (MODE == 2) val = old + val;  // C1 + C2 of the lrp variant
-      return val;
     };
-    constexpr bool kReadsOut = ACCUM || MODE == 2;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          if (gr < T && gc < Nn) {
-            const float old = kReadsOut ? out[gr * Nn + gc] : 0.0f;
-            out[gr * Nn + gc] = finish(X[gr * Nn + gc], old, mi, ni, e);
-          }
-#pragma unroll
-          for (int s = 0; s < NACC; ++s) acc[s][mi][ni][e] = 0.0f;
-        }
-      }
-    if (kStaged) {
-      if (has_next) {
+    load_next(0);
+    store_rows_tile<BM>(smem, ra);
+    store_kn_tile<BN>(smem + A_SZ, rb);
+    __syncthreads();
+    Frag f0, f1;
+    read_frag(f0, 0, 0);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      read_frag(f1, cur, 1);
+      mma_group(f0);
+      if (more) load_next(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frag(f0, cur, 2);
+      mma_group(f1);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frag(f1, cur, 3);
+      mma_group(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
         store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
         store_kn_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
+        __syncthreads();
+        read_frag(f0, cur ^ 1, 0);
       }
-      __syncthreads();
+      mma_group(f1);
+      __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
     }
-    tc = tn;
-  }
+  };
+  if (interior) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (gr < T && gc < Nn) {
+          const float x = X[gr * Nn + gc];
+          const float xp = fmaxf(x, 0.0f), xn = fminf(x, 0.0f);
+          float val;
+          if constexpr (MODE == 0) val = xp * acc[0][mi][ni][e] + xn * acc[1][mi][ni][e];
+          else if constexpr (MODE == 1) val = xp * acc[0][mi][ni][e];
+          else val = xn * acc[0][mi][ni][e];
+          val = scale * val;
+          if constexpr (ACCUM) val = out[gr * Nn + gc] - val;          // alpha*act - beta*inh
+          else if constexpr (MODE == 2) val = out[gr * Nn + gc] + val;  // C1 + C2 of the lrp variant
+          out[gr * Nn + gc] = val;
+        }
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,19 +582,6 @@ inline Tile pick_tile(int64_t T, int64_t n_out, bool one_product = false) {
   return (e1 > e0) ? TILE_128x64 : TILE_128x128;
 }
 
-// grid: one block per tile, or (TE_LINEAR_PERSIST=1) as many co-resident blocks as LDS admits per CU x 256
-template <size_t LDS_BYTES>
-inline int grid_for(int ntiles) {
-  static const int persist = [] {
-    const char* e = getenv("TE_LINEAR_PERSIST");
-    return e ? atoi(e) : 0;
-  }();
-  if (!persist) return ntiles;
-  constexpr int fit = (int)(kLdsPerCU / LDS_BYTES);
-  constexpr int per_cu = fit > 5 ? 5 : fit;
-  return ntiles < kCUs * per_cu ? ntiles : kCUs * per_cu;
-}
-
 template <int ZM, bool SWAP, int BM, int BN>
 inline void launch_k1(const float* X, const float* W, const float* R, const float* Y, const float* bias, float* S1,
                       float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream) {
@@ -594,7 +589,7 @@ inline void launch_k1(const float* X, const float* W, const float* R, const floa
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k1_lds<BM, BN>();
   allow_lds(linear_k1_kernel<ZM, SWAP, BM, BN>, lds);
-  linear_k1_kernel<ZM, SWAP, BM, BN><<<dim3((unsigned)grid_for<lds>(ntiles)), dim3(kThreads), lds, stream>>>(
+  linear_k1_kernel<ZM, SWAP, BM, BN><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
       X, W, R, Y, bias, S1, S2, T, in_f, out_f, nbn, ntiles);
 }
 template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
@@ -604,7 +599,7 @@ inline void launch_k2(const float* S, const float* W, const float* X, float* out
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k2_lds<BM, BN>();
   allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN>, lds);
-  linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN><<<dim3((unsigned)grid_for<lds>(ntiles)), dim3(kThreads), lds, stream>>>(
+  linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
       S, W, X, out, T, out_f, in_f, nbn, ntiles, scale);
 }
 
