@@ -193,6 +193,14 @@ size_t te_rollout_workspace_bytes(int64_t L, int64_t B, int64_t N);
 int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
                    int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream);
 
+/* ---- consumer of a relevance map ---------------------------------------------------
+ * replaces baselines/ViT/imagenet_seg_eval.py:214-222 and generate_visualizations.py:99-100 (per map):
+ * maps [B,g,g] -> heat [B, g*scale, g*scale] = F.interpolate(scale_factor=scale, mode='bilinear') of each map,
+ * then (normalise != 0) (heat - min) / (max - min) per map; fg_mask (optional, NULL to skip) = heat > mean(heat)
+ * as 0/1 floats (Res.gt(Res.mean())). */
+int te_heatmap_f32(const float* maps, float* heat, float* fg_mask, int64_t B, int64_t g, int64_t scale,
+                   int normalise, te_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -344,6 +344,21 @@ def bert_relprop(one_hot: Tensor, cache: dict, num_heads: int, start_layer: int 
 # --------------------------------------------------------------------------------------------
 # downstream consumer: bilinear x16 + min-max      imagenet_seg_eval.py:214-217
 # --------------------------------------------------------------------------------------------
+def heatmap(maps: Tensor, scale: int = 16, normalise: bool = True) -> Tuple[Tensor, Tensor]:
+    """imagenet_seg_eval.py:214-222 per map: maps [B,g*g] -> (heat [B,1,g*s,g*s], fg mask): the reference's own calls
+    (F.interpolate bilinear, whole-tensor min-max at batch 1, Res.gt(Res.mean()))."""
+    B = maps.shape[0]
+    g = int(round((maps.numel() // B) ** 0.5))
+    heats, masks = [], []
+    for i in range(B):
+        res = torch.nn.functional.interpolate(maps[i].reshape(1, 1, g, g), scale_factor=scale, mode="bilinear")
+        if normalise:
+            res = (res - res.min()) / (res.max() - res.min())
+        heats.append(res)
+        masks.append(res.gt(res.mean()).type(res.type()))
+    return torch.cat(heats, 0), torch.cat(masks, 0)
+
+
 def minmax_normalise(m: Tensor) -> Tensor:
     """Per-map min-max normalisation used by the parity statistic."""
     flat = m.reshape(m.shape[0], -1)

@@ -67,6 +67,19 @@ def test_vit_tiny_golden(golden_vit_tiny, variant):
     _assert_map(f"vit_tiny.{variant}.rollout", out, g[f"{variant}.rollout_sl0"])
 
 
+def test_generate_visualization_api(golden_vit_tiny):
+    """The notebooks' generate_visualization helper: [3,H,W] image -> uint8 [H,W,3] overlay (API surface)."""
+    from transformer_explainability_amd import vit
+    from transformer_explainability_amd.generators import LRP, generate_visualization
+    g = golden_vit_tiny
+    model = vit.VisionTransformer(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10,
+                                  qkv_bias=True).eval()
+    model.load_state_dict(_state(g))
+    model.to(dev())
+    vis = generate_visualization(LRP(model), g["x"][0], class_index=3)
+    assert vis.shape == (32, 32, 3) and vis.dtype.name == "uint8" and vis.max() == 255
+
+
 def test_vit_tiny_kernels_on_reference_cache(golden_vit_tiny):
     """Relprop kernels fed the REFERENCE's cached tensors (no forward of ours involved): per-block
     attn_cam and the token relevance must match the reference's own intermediates."""

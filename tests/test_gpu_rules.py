@@ -374,3 +374,21 @@ def test_rule_modules_match_reference_api(golden_rules):
     isel = rules.IndexSelect()
     isel(g["index_select.X"].to(d), 1, torch.tensor(0, device=d))
     check("module.index_select", isel.relprop(g["index_select.R"].to(d), 1), g["index_select.out"], 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ consumer (8f.2)
+@pytest.mark.parametrize("B,g,scale", [(3, 14, 16), (1, 24, 16), (2, 7, 4), (1, 1, 16)])
+@pytest.mark.parametrize("normalise", [True, False])
+def test_heatmap_consumer(B, g, scale, normalise):
+    """bilinear x16 + per-map min-max + mean threshold vs the reference's own torch calls on the CPU."""
+    from transformer_explainability_amd import ops
+    if g == 1 and normalise:
+        pytest.skip("a constant map has max == min (0/0 in the reference too)")
+    maps = rnd((B, g * g), 61, 1e-4).abs()
+    heat, mask = ops.heatmap(maps.to(dev()), scale=scale, normalise=normalise, with_mask=True)
+    ref_h, ref_m = O.heatmap(maps, scale=scale, normalise=normalise)
+    check(f"heatmap({B},{g},{scale},{normalise})", heat, ref_h, 2e-6)
+    # the mask may differ only where a pixel sits within rounding of the mean
+    disagree = (mask.cpu() != ref_m)
+    near = (ref_h - ref_h.reshape(B, -1).mean(1).reshape(B, 1, 1, 1)).abs() <= 1e-6 * ref_h.abs().max()
+    assert not (disagree & ~near).any()

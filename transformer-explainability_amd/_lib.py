@@ -52,6 +52,7 @@ SIGNATURES = {
     "te_clone_relprop_f32": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     "te_index_select_relprop_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "te_gradcam_headmean_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "te_heatmap_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
     "te_rollout_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_rollout_f32": (_I, [_P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
 }

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libte_relprop.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 
 SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_attn.hip", "te_attn_mfma.hip",
-           "te_rollout.hip"]
+           "te_rollout.hip", "te_heatmap.hip"]
 
 CXXFLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

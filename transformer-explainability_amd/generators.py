@@ -90,6 +90,36 @@ class LRP:
         return self.model.relprop(one_hot, method=method, is_ablation=is_ablation, start_layer=start_layer, **kwargs)
 
 
+def _jet_bgr(mask01: np.ndarray) -> np.ndarray:
+    """COLORMAP_JET as a formula (cv2 is not a dependency here): the standard piecewise-linear jet, returned in
+    OpenCV's BGR channel order like cv2.applyColorMap(np.uint8(255 * mask), cv2.COLORMAP_JET) / 255.
+    (Parity with cv2's 256-entry LUT is not pinned: no cv2 in the build image.)"""
+    x = np.floor(255.0 * mask01) / 255.0                      # np.uint8(255 * mask) quantisation
+    r = np.clip(1.5 - np.abs(4.0 * x - 3.0), 0.0, 1.0)
+    g = np.clip(1.5 - np.abs(4.0 * x - 2.0), 0.0, 1.0)
+    b = np.clip(1.5 - np.abs(4.0 * x - 1.0), 0.0, 1.0)
+    return np.stack([b, g, r], axis=-1).astype(np.float32)
+
+
+def generate_visualization(attribution_generator, original_image, class_index=None, method="transformer_attribution",
+                           start_layer=0):
+    """The notebooks' helper (example.ipynb:55-66, Transformer_explainability.ipynb:1149): relevance map of one image
+    [3,H,W] -> bilinear x16 -> min-max -> JET overlay, uint8 [H,W,3].  The reference closes over a global
+    ``attribution_generator``; here it is the first argument.  Up-sampling + normalisation run on the device
+    (te_heatmap_f32)."""
+    dev = next(attribution_generator.model.parameters()).device
+    maps = attribution_generator.generate_LRP(original_image.unsqueeze(0).to(dev), method=method, index=class_index,
+                                              start_layer=start_layer).detach()
+    patch = attribution_generator.model.patch_embed.patch_size[0]
+    heat = ops.heatmap(maps, scale=patch, normalise=True)[0, 0].cpu().numpy()
+    img = original_image.permute(1, 2, 0).detach().cpu().numpy()
+    img = (img - img.min()) / (img.max() - img.min())
+    cam = _jet_bgr(heat) + np.float32(img)                     # show_cam_on_image (example.ipynb:47-52)
+    cam = cam / np.max(cam)
+    vis = np.uint8(255 * cam)
+    return np.ascontiguousarray(vis[..., ::-1])                # cv2.cvtColor(vis, cv2.COLOR_RGB2BGR)
+
+
 class GraphedLRP:
     """One ``LRP.generate_LRP`` pass for a FIXED input shape captured in a HIP graph (forward, attention-gradient
     backward and every relprop kernel: ~1100 launches for ViT-B) and replayed per batch.  The pass is launch-latency

@@ -289,3 +289,21 @@ def rollout(cams: Tensor, start_layer: int = 0, normalise: bool = False, cls_fix
         _lib.check(lib.te_rollout_f32(_ptr(cams), L, int(start_layer), B, N, flags, _ptr(joint), _ptr(ws), ws.numel(),
                                       _stream(cams)), "te_rollout_f32")
     return joint
+
+
+# ---------------------------------------------------------------------------------------- 8f.2 consumer
+def heatmap(maps: Tensor, scale: int = 16, normalise: bool = True, with_mask: bool = False):
+    """maps [B, g*g] or [B,1,g,g] -> heat [B,1,g*scale,g*scale]: bilinear up-sampling + per-map min-max
+    (imagenet_seg_eval.py:214-217); with_mask also returns the mean-threshold foreground mask (:219-221)."""
+    m = _c(maps)
+    B = m.shape[0]
+    g = int(round((m.numel() // B) ** 0.5))
+    if g * g * B != m.numel():
+        raise _lib.TeError(f"heatmap: {tuple(maps.shape)} is not a batch of square patch maps")
+    side = g * scale
+    heat = torch.empty((B, 1, side, side), dtype=torch.float32, device=m.device)
+    mask = torch.empty_like(heat) if with_mask else None
+    with _on_device(m) as lib:
+        _lib.check(lib.te_heatmap_f32(_ptr(m), _ptr(heat), _ptr(mask), B, g, int(scale), int(bool(normalise)), _stream(m)),
+                   "te_heatmap_f32")
+    return (heat, mask) if with_mask else heat
