@@ -200,7 +200,9 @@ def main():
     counter = [0]
 
     graphed = None
-    if args.graph == "on" and args.inflight == 1 and args.streams == 1:
+    # (multi-rank runs stay eager: RCCL's watchdog thread may touch the HIP runtime while a capture is open, and the
+    #  step is GPU-bound either way -- replay only frees the host)
+    if args.graph == "on" and args.inflight == 1 and args.streams == 1 and world == 1:
         from transformer_explainability_amd.generators import GraphedLRP
         try:
             graphed = GraphedLRP(lrp, x, method="transformer_attribution", start_layer=args.start_layer)
