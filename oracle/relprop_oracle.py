@@ -21,8 +21,7 @@ reference takes over "the whole tensor" is taken per sample here.
 """
 from __future__ import annotations
 
-import math
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 

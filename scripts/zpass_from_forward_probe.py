@@ -1,4 +1,4 @@
-import sys, os, torch
+import sys, torch
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 from gpu_util import map_stats
 from oracle import relprop_oracle as O

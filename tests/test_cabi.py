@@ -1,6 +1,5 @@
 """C-ABI surface checks that need no GPU: the library is built, loads through ctypes, exports every
 symbol include/te_relprop.h declares, and the host-side workspace queries / argument validation work."""
-import ctypes
 import os
 import re
 

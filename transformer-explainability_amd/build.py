@@ -14,7 +14,6 @@ import argparse
 import os
 import shutil
 import subprocess
-import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)

@@ -6,7 +6,7 @@ relprop rules; see include/te_relprop.h for the exact semantics and reference ci
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 

@@ -10,7 +10,7 @@ code).
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+from typing import Tuple
 
 import torch
 import torch.distributed as dist

@@ -15,8 +15,6 @@ What differs from the reference (by design, results identical at batch 1):
 """
 from __future__ import annotations
 
-import math
-
 import torch
 import torch.nn as nn
 
