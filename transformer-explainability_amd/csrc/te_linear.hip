@@ -240,15 +240,11 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if constexpr (FWD) {
-        float aa[MI], ab[NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) aa[mi] = te_abs(f.a[mi][j]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) ab[ni] = te_abs(f.b[ni][j]);
+        // |X| and |W| were formed when the tiles were staged (abs_regs): a plain GEMM inner loop, no VALU
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(aa[mi], ab[ni], acc[0][mi][ni]);
+          for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(f.a[mi][j], f.b[ni][j], acc[0][mi][ni]);
       } else {
         float ap[MI], an[MI], bp[NI], bn[NI];
 #pragma unroll
@@ -287,7 +283,22 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
         load_rows_tile<BN>(W, Nn, K, tc.col0, (int64_t)kt * BK, rb);
       }
     };
+    // one-product Z-pass: the operands are |X| and |W|; clearing the sign bits once per staged element (6 VALU ops
+    // per thread and K-step, next to the LDS stores) instead of once per fragment use inside the MFMA stream
+    auto abs_regs = [&]() __attribute__((always_inline)) {
+      if constexpr (FWD) {
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[i][e] = te_abs(ra[i][e]);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rb[i][e] = te_abs(rb[i][e]);
+      }
+    };
     load_next(0);
+    abs_regs();
     store_rows_tile<BM>(smem, ra);
     store_rows_tile<BN>(smem + A_SZ, rb);
     __syncthreads();
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
       mma_group(f0);
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
+        abs_regs();
         store_rows_tile<BM>(smem + (cur ^ 1) * STAGE, ra);
         store_rows_tile<BN>(smem + (cur ^ 1) * STAGE + A_SZ, rb);
         __syncthreads();
