@@ -80,6 +80,22 @@ def test_generate_visualization_api(golden_vit_tiny):
     assert vis.shape == (32, 32, 3) and vis.dtype.name == "uint8" and vis.max() == 255
 
 
+def test_baselines_rollout(golden_vit_tiny):
+    """Baselines.generate_rollout (ViT_explanation_generator.py:74-83): head-averaged attention through the
+    row-normalised rollout kernel vs the oracle's rollout on the same attention maps."""
+    from transformer_explainability_amd import vit
+    from transformer_explainability_amd.generators import Baselines
+    g = golden_vit_tiny
+    model = vit.VisionTransformer(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10,
+                                  qkv_bias=True).eval()
+    model.load_state_dict(_state(g))
+    model.to(dev())
+    out = Baselines(model).generate_rollout(g["x"].to(dev()), start_layer=1)
+    mats = [blk.attn.get_attention_map().detach().mean(dim=1).cpu() for blk in model.blocks]
+    ref = O.rollout(mats, 1, normalise=True)[:, 0, 1:]
+    check("baselines.rollout", out, ref, 1e-5)
+
+
 def test_vit_tiny_kernels_on_reference_cache(golden_vit_tiny):
     """Relprop kernels fed the REFERENCE's cached tensors (no forward of ours involved): per-block
     attn_cam and the token relevance must match the reference's own intermediates."""

@@ -28,6 +28,9 @@ def install_dropin() -> str:
     import os
     import sys
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
-    if d not in sys.path:
-        sys.path.insert(0, d)
+    # the evaluation scripts run from baselines/ViT and import ``ViT_LRP`` / ``ViT_new`` / ``ViT_explanation_generator``
+    # by their bare names (imagenet_seg_eval.py:19-22), the BERT pipeline uses package paths (bert_pipeline.py:17)
+    for p in (os.path.join(d, "baselines", "ViT"), d):
+        if p not in sys.path:
+            sys.path.insert(0, p)
     return d

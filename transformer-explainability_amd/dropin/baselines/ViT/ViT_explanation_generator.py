@@ -1,6 +1,4 @@
-"""Drop-in for baselines/ViT/ViT_explanation_generator.py of the reference (class LRP).
-
-The attention-only `Baselines` class (no relprop) is outside the accelerated path."""
+"""Drop-in for baselines/ViT/ViT_explanation_generator.py of the reference (classes LRP and Baselines)."""
 import os as _os
 import sys as _sys
 
@@ -8,7 +6,7 @@ _root = _os.path.abspath(_os.path.join(_os.path.dirname(__file__), "..", "..", "
 if _root not in _sys.path:
     _sys.path.insert(0, _root)
 from transformer_explainability_amd import ops as _ops  # noqa: E402
-from transformer_explainability_amd.generators import LRP  # noqa: E402,F401
+from transformer_explainability_amd.generators import LRP, Baselines  # noqa: E402,F401
 
 
 def compute_rollout_attention(all_layer_matrices, start_layer=0):

@@ -90,6 +90,40 @@ class LRP:
         return self.model.relprop(one_hot, method=method, is_ablation=is_ablation, start_layer=start_layer, **kwargs)
 
 
+class Baselines:
+    """baselines/ViT/ViT_explanation_generator.py:44-83: the two attention-only baselines (no relprop; off the
+    accelerated path, here so that the evaluation scripts' ``from ViT_explanation_generator import Baselines, LRP``
+    resolves).  Batched: B inputs -> B maps."""
+
+    def __init__(self, model):
+        self.model = model
+        self.model.eval()
+
+    def generate_cam_attn(self, input, index=None):
+        """attention GradCAM of the last block (:50-72): per-head gradient mean x attention, class-token row."""
+        output = self.model(input, register_hook=True)
+        one_hot = _one_hot(output, index)
+        last = self.model.blocks[-1].attn
+        (grad,) = torch.autograd.grad(torch.sum(one_hot * output), [last.get_attention_map()])
+        last.save_attn_gradients(grad)
+        B, H, N, _ = grad.shape
+        side = int(round((N - 1) ** 0.5))
+        cam = last.get_attention_map().detach()[:, :, 0, 1:].reshape(B, H, side, side)
+        g = grad[:, :, 0, 1:].reshape(B, H, side, side).mean(dim=[2, 3], keepdim=True)
+        cam = (cam * g).mean(1).clamp(min=0)
+        lo = cam.amin(dim=(1, 2), keepdim=True)
+        hi = cam.amax(dim=(1, 2), keepdim=True)
+        cam = (cam - lo) / (hi - lo)
+        return cam[0] if B == 1 else cam
+
+    def generate_rollout(self, input, start_layer=0):
+        """attention rollout (:74-83): head-averaged attention, identity added, rows normalised, chained."""
+        self.model(input)
+        mats = [blk.attn.get_attention_map().detach().mean(dim=1) for blk in self.model.blocks]
+        joint = ops.rollout(torch.stack(mats, 0), start_layer=start_layer, normalise=True)
+        return joint[:, 0, 1:]
+
+
 def _jet_bgr(mask01: np.ndarray) -> np.ndarray:
     """COLORMAP_JET as a formula (cv2 is not a dependency here): the standard piecewise-linear jet, returned in
     OpenCV's BGR channel order like cv2.applyColorMap(np.uint8(255 * mask), cv2.COLORMAP_JET) / 255.

@@ -73,6 +73,9 @@ def make_vit_module(L):
         # accessors of ViT_LRP.py:102-130
         def get_attn(self): return self.attn
         def save_attn(self, attn): self.attn = attn
+        # accessor names of the plain (non-LRP) model, baselines/ViT/ViT_new.py:78-88
+        def get_attention_map(self): return self.attn
+        def save_attention_map(self, attn): self.attn = attn
         def save_attn_cam(self, cam): self.attn_cam = cam
         def get_attn_cam(self): return self.attn_cam
         def get_v(self): return self.v
@@ -234,7 +237,8 @@ def make_vit_module(L):
         def no_weight_decay(self):
             return {'pos_embed', 'cls_token'}
 
-        def forward(self, x):
+        def forward(self, x, register_hook=False):
+            # register_hook (ViT_new.py:195): the attention-gradient hook is always registered when a graph is built
             B = x.shape[0]
             x = self.patch_embed(x)
             x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
