@@ -201,6 +201,35 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
 int te_heatmap_f32(const float* maps, float* heat, float* fg_mask, int64_t B, int64_t g, int64_t scale,
                    int normalise, te_stream_t stream);
 
+/* ---- Conv2d.relprop, z^B rule of the patch embedding (method="full") ------------------
+ * replaces modules/layers_ours.py:242-256 (= modules/layers_lrp.py:223-237), the `X.shape[1] == 3` branch, for a
+ * convolution with stride == kernel == p and no padding (baselines/ViT/ViT_LRP.py:215-242, PatchEmbed):
+ *   Za = conv(X,W) - conv(L,W+) - conv(H,W-) + 1e-9 ; S = R / Za ; out = X convT(S,W) - L convT(S,W+) - H convT(S,W-)
+ * with L / H = per-sample pixel min / max.  R: relevance of the conv output in TOKEN-MAJOR layout [B, P, E]
+ * (P = (H/p)(W/p); what PatchEmbed.relprop holds before its transpose), consecutive samples r_bs floats apart
+ * (r_bs >= P*E; (P+1)*E when R is cam[:, 1:] of a [B, P+1, E] tensor).  X [B,C,H,W]; W [E,C,p,p]; Y [B,E,H/p,W/p] =
+ * the layer's forward output (conv(X,W) is taken as Y - bias; bias may be NULL); out [B,C,H,W].
+ * flags: TE_IMPL_SIMPLE selects the one-thread-per-element C-pass. */
+size_t te_conv2d_zb_relprop_workspace_bytes(int64_t B, int64_t C, int64_t H, int64_t W, int64_t E, int64_t p);
+int te_conv2d_zb_relprop_f32(const float* R, int64_t r_bs, const float* X, const float* W, const float* Y,
+                             const float* bias, float* out, int64_t B, int64_t C, int64_t H, int64_t W_, int64_t E,
+                             int64_t p, int flags, void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* ---- perturbation-test input builder ---------------------------------------------------
+ * replaces baselines/ViT/pertubation_eval_from_hdf5.py:88-101 for ALL perturbation steps of a batch in two launches:
+ *   for each step s:  idx = topk(vis[b], ks[s]) ; out[s][b][c][idx] = 0 for every channel c, data elsewhere ;
+ *                     out = (out - mean[c]) / std[c]
+ * vis [B,HW] relevance per pixel (negate it first for the script's --neg mode); data [B,C,HW] pixels; ks: HOST array
+ * of n_steps pixel counts (int(base_size * step)), clamped to [0, HW]; mean / std: HOST arrays [C] (NULL = 0 / 1);
+ * out [n_steps,B,C,HW].  Equal relevance values are removed in ascending pixel-index order (torch.topk leaves the
+ * order among ties unspecified).  NaN relevance counts as largest, as in torch.topk. */
+#define TE_PERTURB_MAX_STEPS 16
+#define TE_PERTURB_MAX_CHANNELS 4
+size_t te_perturb_workspace_bytes(int64_t B, int64_t n_steps);
+int te_perturb_f32(const float* vis, const float* data, float* out, int64_t B, int64_t C, int64_t HW,
+                   const int64_t* ks, int64_t n_steps, const float* mean, const float* std_, void* ws,
+                   size_t ws_bytes, te_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,10 @@ def vit_cache_from_model(model):
             # reproduces on that device): unscaled q k^T and attn v
             "z_qk": _cpu(getattr(blk.attn.matmul1, "Y", None)), "z_av": _cpu(getattr(blk.attn.matmul2, "Y", None))})
     return {"head_x": _cpu(model.head.X), "head_w": _cpu(model.head.weight), "pool_x": _cpu(model.pool.X),
-            "blocks": blocks}
+            "blocks": blocks,
+            # method="full" only: position-embedding Add and the patch-embedding convolution
+            "pos_add_x0": _cpu(model.add.X[0]), "pos_embed": _cpu(model.add.X[1]),
+            "patch_x": _cpu(model.patch_embed.proj.X), "patch_w": _cpu(model.patch_embed.proj.weight)}
 
 
 def bert_cache_from_model(model):

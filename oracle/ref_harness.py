@@ -71,6 +71,39 @@ def load_reference_vit():
     return mods
 
 
+def load_reference_perturbation_eval():
+    """Import baselines/ViT/pertubation_eval_from_hdf5.py as a module (its ``eval(args)`` reads the loader, dataset,
+    model and device from module globals, which the caller sets).  Stubs: ``dataset.expl_hdf5`` (needs h5py, absent
+    here; only the class name is imported at module level)."""
+    _cuda_identity_shim()
+    import importlib.util
+    stub_pkg = types.ModuleType("dataset")
+    stub_mod = types.ModuleType("dataset.expl_hdf5")
+    stub_mod.ImagenetResults = object
+    stub_pkg.expl_hdf5 = stub_mod
+    vit_dir = os.path.join(REFERENCE_ROOT, "baselines", "ViT")
+    with reference_on_path():
+        saved = {k: sys.modules.get(k) for k in ("dataset", "dataset.expl_hdf5", "ViT_explanation_generator", "ViT_new")}
+        sys.modules["dataset"], sys.modules["dataset.expl_hdf5"] = stub_pkg, stub_mod
+        for k in ("ViT_explanation_generator", "ViT_new"):
+            sys.modules.pop(k, None)
+        sys.path.insert(0, vit_dir)
+        try:
+            spec = importlib.util.spec_from_file_location("ref_pertubation_eval",
+                                                          os.path.join(vit_dir, "pertubation_eval_from_hdf5.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            vnew = sys.modules["ViT_new"]
+        finally:
+            sys.path.remove(vit_dir)
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    return mod, vnew
+
+
 def load_reference_bert():
     """Returns reference BERT modules with the Appendix-C compat shims applied."""
     _cuda_identity_shim()

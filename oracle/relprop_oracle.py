@@ -294,6 +294,45 @@ def vit_relprop(one_hot: Tensor, cache: dict, num_heads: int, start_layer: int =
 
 
 # --------------------------------------------------------------------------------------------
+# 8f.3  Conv2d.relprop, z^B rule (image-input branch)     modules/layers_ours.py:233-256
+#       + VisionTransformer.relprop(method="full")        baselines/ViT/ViT_LRP.py:337-343
+# --------------------------------------------------------------------------------------------
+def conv2d_zb_relprop(R: Tensor, X: Tensor, W: Tensor, stride, padding=0) -> Tensor:
+    """R [B,E,Ho,Wo], X [B,3,H,W], W [E,3,kh,kw] -> [B,3,H,W].  L / H are per-sample pixel min / max (:245-250);
+    gradprop2 (:233-240) is the transposed convolution with the output padding that restores X's size."""
+    import torch.nn.functional as F
+    pw, nw = W.clamp(min=0), W.clamp(max=0)
+    lo = X.amin(dim=(1, 2, 3), keepdim=True)
+    hi = X.amax(dim=(1, 2, 3), keepdim=True)
+    L = X * 0 + lo
+    Hh = X * 0 + hi
+    za = (F.conv2d(X, W, None, stride, padding) - F.conv2d(L, pw, None, stride, padding)
+          - F.conv2d(Hh, nw, None, stride, padding) + 1e-9)
+    S = R / za
+    st = (stride, stride) if isinstance(stride, int) else tuple(stride)
+    pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
+    op = tuple(X.shape[2 + i] - ((za.shape[2 + i] - 1) * st[i] - 2 * pd[i] + W.shape[2 + i]) for i in range(2))
+
+    def g(w):
+        return F.conv_transpose2d(S, w, None, st, pd, op)
+    return X * g(W) - L * g(pw) - Hh * g(nw)
+
+
+def vit_full_tail(cam: Tensor, cache: dict, variant: str = "ours") -> Tensor:
+    """ViT_LRP.py:337-343 on the token relevance `cam` [B,N,C] left by the block stack: position-embedding Add
+    (pos_add_x0 [B,N,C] + pos_embed [1,N,C]), drop the class token, z^B rule of the patch embedding
+    (patch_x [B,3,H,W], patch_w [E,3,p,p]), sum over the colour channels -> [B,H,W]."""
+    pos = cache["pos_embed"].expand_as(cache["pos_add_x0"])
+    cam, _ = add_relprop(cam, cache["pos_add_x0"], pos, variant)
+    cam = cam[:, 1:]
+    B, P, E = cam.shape
+    p = cache["patch_w"].shape[-1]
+    Hp, Wp = cache["patch_x"].shape[2] // p, cache["patch_x"].shape[3] // p
+    R = cam.transpose(1, 2).reshape(B, E, Hp, Wp)
+    return conv2d_zb_relprop(R, cache["patch_x"], cache["patch_w"], p).sum(dim=1)
+
+
+# --------------------------------------------------------------------------------------------
 # BERT layer / model relprop            BERT.py:521-530,240-247,367-409,427-434,451-456,474-487
 # --------------------------------------------------------------------------------------------
 def bert_layer_relprop(cam: Tensor, lay: dict, num_heads: int, alpha: float = 1.0,
@@ -364,3 +403,25 @@ def minmax_normalise(m: Tensor) -> Tensor:
     lo = flat.min(dim=1, keepdim=True).values
     hi = flat.max(dim=1, keepdim=True).values
     return ((flat - lo) / (hi - lo)).reshape(m.shape)
+
+
+# --------------------------------------------------------------------------------------------
+# 8f.4  perturbation inputs            baselines/ViT/pertubation_eval_from_hdf5.py:88-101
+# --------------------------------------------------------------------------------------------
+def perturb(vis: Tensor, data: Tensor, ks: Sequence[int], mean=None, std=None) -> Tensor:
+    """vis [B,HW], data [B,C,H,W] -> [S,B,C,H,W], the script's own torch calls per step (topk + scatter_ + normalise).
+    torch.topk's choice among tied values is unspecified; here a stable descending sort fixes it to ascending index
+    order, the rule the device kernel documents."""
+    B, C = data.shape[:2]
+    outs = []
+    order = torch.sort(vis.reshape(B, -1), dim=-1, descending=True, stable=True).indices
+    for k in ks:
+        k = max(0, min(int(k), order.shape[1]))
+        idx = order[:, :k].unsqueeze(1).repeat(1, C, 1)
+        d = data.clone().reshape(B, C, -1).scatter_(-1, idx, 0).reshape(data.shape)
+        if mean is not None:
+            m = torch.tensor(mean, dtype=d.dtype).reshape(1, C, 1, 1)
+            sd = torch.tensor(std, dtype=d.dtype).reshape(1, C, 1, 1)
+            d = (d - m) / sd
+        outs.append(d)
+    return torch.stack(outs, 0)

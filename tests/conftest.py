@@ -74,3 +74,13 @@ def golden_vit_b16():
 @pytest.fixture(scope="session")
 def golden_bert_base():
     return load_golden("bert_base.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_methods():
+    return load_golden("methods.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_perturbation():
+    return load_golden("perturbation.npz")

@@ -13,6 +13,11 @@ and seeded ``randn`` inputs, torch CPU fp32.  Fixtures:
   vit_b16.npz     ViT-B/16 224^2: generate_LRP maps for 2 images (weights regenerated from the seed)
   bert_tiny.npz   3-layer BERT (dim 64, 4 heads, 24 tokens, 6 padded): full cache + intermediates
   bert_base.npz   BERT-base, 128 tokens (28 padded): generate_LRP vectors (weights from the seed)
+  methods.npz     SURVEY.md 8f.3: Conv2d z^B rule called directly; method="full" / second_layer / last_layer_attn /
+                  ablation maps of the tiny ViT (weights = vit_tiny.npz state); Baselines (cam_attn, rollout) on a
+                  narrow 14x14-patch ViT_new; the other Generator methods on the tiny BERT (weights = bert_tiny.npz)
+  perturbation.npz  SURVEY.md 8f.4: the six result arrays of pertubation_eval_from_hdf5.py's eval(args), run on a
+                  narrow ViT_new and seeded inputs (positive / negative / fixed-pixel-count modes)
 """
 import os
 import sys
@@ -279,10 +284,126 @@ def make_bert(tiny: bool):
     print(name, len(out), "arrays")
 
 
+# ------------------------------------------------------------------------------------------
+def make_methods():
+    vit = rh.load_reference_vit()
+    out = {}
+    r = rh.seeded_randn
+    # ---- Conv2d z^B rule, called directly on a patch convolution (stride == kernel)
+    for variant, mod in (("ours", vit["layers_ours"]), ("lrp", vit["layers_lrp"])):
+        conv = mod.Conv2d(3, 12, kernel_size=4, stride=4)
+        with torch.no_grad():
+            conv.weight.copy_(0.2 * r((12, 3, 4, 4), 61))
+            conv.bias.copy_(0.1 * r((12,), 62))
+        X = r((2, 3, 8, 12), 63)
+        conv(X)
+        R = r((2, 12, 2, 3), 64) * 0.01
+        out.update({f"conv_{variant}.X": npy(X), f"conv_{variant}.W": npy(conv.weight), f"conv_{variant}.b": npy(conv.bias),
+                    f"conv_{variant}.R": npy(R), f"conv_{variant}.out": npy(conv.relprop(R, 1))})
+
+    # ---- the other method= branches of the tiny ViT (ViT_LRP.py:337-398)
+    cfg = dict(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10, qkv_bias=True)
+    x = r((2, 3, 32, 32), 1)
+    for variant, modname in (("ours", "ViT_LRP"), ("lrp", "ViT_orig_LRP")):
+        model = vit[modname].VisionTransformer(**cfg).eval()
+        rh.synthetic_init(model, 0)
+        out[f"{variant}.state_checksum"] = np.float64(rh.state_checksum(model))
+        out[f"{variant}.full"] = npy(run_vit(model, vit["gen"], x, "full", 0))
+        out[f"{variant}.second_layer"] = npy(run_vit(model, vit["gen"], x, "second_layer", 0).reshape(2, -1))
+        out[f"{variant}.last_layer_attn"] = npy(run_vit(model, vit["gen"], x, "last_layer_attn", 0).reshape(2, -1))
+        gen = vit["gen"].LRP(model)
+        abl = [gen.generate_LRP(x[i:i + 1], method="last_layer", is_ablation=True).detach().reshape(1, -1)
+               for i in range(2)]
+        out[f"{variant}.last_layer_ablation"] = npy(torch.cat(abl, 0))
+        out[f"{variant}.rollout_sl1"] = npy(run_vit(model, vit["gen"], x, "rollout", 1))
+
+    # ---- Baselines on the hook-only model (ViT_new.py); generate_cam_attn hard-codes a 14 x 14 patch grid (:65-66)
+    with rh.reference_on_path():
+        import importlib
+        vnew = importlib.import_module("baselines.ViT.ViT_new")
+    bcfg = dict(img_size=224, patch_size=16, embed_dim=64, depth=2, num_heads=4, num_classes=10, qkv_bias=True)
+    model = vnew.VisionTransformer(**bcfg).eval()
+    rh.synthetic_init(model, 0)
+    xb = r((2, 3, 224, 224), 2)
+    base = vit["gen"].Baselines(model)
+    out["baselines.x_seed"] = np.int64(2)
+    out["baselines.logits"] = npy(model(xb))
+    out["baselines.cam_attn"] = npy(torch.stack([base.generate_cam_attn(xb[i:i + 1]).detach() for i in range(2)]))
+    out["baselines.cam_attn_idx3"] = npy(base.generate_cam_attn(xb[:1], index=3).detach())
+    for sl in (0, 1):
+        out[f"baselines.rollout_sl{sl}"] = npy(torch.cat([base.generate_rollout(xb[i:i + 1], start_layer=sl).detach()
+                                                          for i in range(2)]))
+    for k_, v_ in model.state_dict().items():
+        out[f"baselines.state.{k_}"] = npy(v_)
+
+    # ---- the other Generator methods on the tiny BERT (ExplanationGenerator.py:62-155)
+    bert = rh.load_reference_bert()
+    from transformers import BertConfig
+    bcfg = BertConfig(vocab_size=100, hidden_size=64, num_hidden_layers=3, num_attention_heads=4,
+                      intermediate_size=128, max_position_embeddings=40, num_labels=2)
+    bcfg.return_dict = False
+    ids, mask = bert_inputs(2, 24, 6, 100, 1)
+    bmodel = bert["cls"].BertForSequenceClassification(bcfg).eval()
+    rh.synthetic_init(bmodel, 0)
+    out["bert.state_checksum"] = np.float64(rh.state_checksum(bmodel))
+    gen = bert["gen"].Generator(bmodel)
+
+    def per_sample(fn, **kw):
+        return npy(torch.cat([fn(input_ids=ids[i:i + 1], attention_mask=mask[i:i + 1], **kw).detach().clone()
+                              for i in range(2)]))
+    out["bert.last_layer"] = per_sample(gen.generate_LRP_last_layer)
+    out["bert.full_lrp"] = per_sample(gen.generate_full_lrp)
+    out["bert.attn_last_layer"] = per_sample(gen.generate_attn_last_layer)
+    out["bert.rollout_sl0"] = per_sample(gen.generate_rollout, start_layer=0)
+    out["bert.rollout_sl1"] = per_sample(gen.generate_rollout, start_layer=1)
+    out["bert.attn_gradcam"] = per_sample(gen.generate_attn_gradcam)
+    np.savez_compressed(os.path.join(HERE, "methods.npz"), **out)
+    print("methods.npz", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------------------
+PERTURB_CFG = dict(img_size=224, patch_size=16, embed_dim=64, depth=2, num_heads=4, num_classes=10, qkv_bias=True)
+
+
+def perturbation_inputs():
+    """Seeded inputs of the perturbation fixture (regenerated by the tests): pixels in [0,1], a tie-free relevance
+    value per pixel (torch.topk leaves the order among ties unspecified), labels."""
+    g = torch.Generator().manual_seed(7)
+    data = torch.rand((4, 3, 224, 224), generator=g)
+    # a random permutation of 50,176 DISTINCT values: torch.topk leaves the order among ties unspecified, and 50k
+    # randn draws do contain equal pairs
+    vis = torch.stack([torch.randperm(224 * 224, generator=g) for _ in range(4)]).float().reshape(4, 1, 224, 224)
+    vis = vis / (224 * 224) - 0.5
+    target = torch.tensor([1, 4, 7, 2])
+    return data, vis, target
+
+
+def make_perturbation():
+    """Runs the reference's own eval(args) (pertubation_eval_from_hdf5.py:25-144) on two loader batches of 2."""
+    import argparse
+    import tempfile
+    mod, vnew = rh.load_reference_perturbation_eval()
+    model = vnew.VisionTransformer(**PERTURB_CFG).eval()
+    rh.synthetic_init(model, 0)
+    data, vis, target = perturbation_inputs()
+    out = {"state_checksum": np.float64(rh.state_checksum(model)), "logits": npy(model(mod.normalize(data.clone())))}
+    loader = [(data[:2], vis[:2], target[:2]), (data[2:], vis[2:], target[2:])]
+    for tag, scale, neg in (("per_neg", "per", True), ("per_pos", "per", False), ("abs_neg", "100", True)):
+        with tempfile.TemporaryDirectory() as tmp:
+            mod.imagenet_ds, mod.sample_loader, mod.model, mod.device = [0] * 4, loader, model, torch.device("cpu")
+            args = argparse.Namespace(scale=scale, neg=neg, wrong=False, experiment_dir=tmp)
+            with torch.no_grad():
+                mod.eval(args)
+            for f in sorted(os.listdir(tmp)):
+                out[f"{tag}.{f}"] = np.load(os.path.join(tmp, f))
+    np.savez_compressed(os.path.join(HERE, "perturbation.npz"), **out)
+    print("perturbation.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not rh.reference_available():
         sys.exit("reference checkout not found at " + rh.REFERENCE_ROOT)
-    which = sys.argv[1:] or ["rules", "vit_tiny", "vit_b16", "bert_tiny", "bert_base"]
+    which = sys.argv[1:] or ["rules", "vit_tiny", "vit_b16", "bert_tiny", "bert_base", "methods", "perturbation"]
     if "rules" in which:
         make_rules()
     if "vit_tiny" in which:
@@ -293,3 +414,7 @@ if __name__ == "__main__":
         make_bert(True)
     if "bert_base" in which:
         make_bert(False)
+    if "methods" in which:
+        make_methods()
+    if "perturbation" in which:
+        make_perturbation()

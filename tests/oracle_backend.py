@@ -64,7 +64,15 @@ def rollout(cams, start_layer=0, normalise=False, cls_fixup=False):
     return joint
 
 
-_NAMES = ["linear_relprop", "matmul_relprop_av", "matmul_relprop_qk", "add_relprop", "clone_relprop",
+def conv2d_zb_relprop(R, X, W, Y, bias=None):
+    return O.conv2d_zb_relprop(R.contiguous(), X, W.detach(), W.shape[-1])   # Y / bias: a device-side shortcut only
+
+
+def perturb(vis, data, ks, mean=None, std=None):
+    return O.perturb(vis.reshape(data.shape[0], -1), data, ks, mean, std)
+
+
+_NAMES = ["perturb", "conv2d_zb_relprop", "linear_relprop", "matmul_relprop_av", "matmul_relprop_qk", "add_relprop", "clone_relprop",
           "index_select_relprop", "gradcam_headmean", "rollout"]
 
 

@@ -67,6 +67,74 @@ def test_vit_tiny_golden(golden_vit_tiny, variant):
     _assert_map(f"vit_tiny.{variant}.rollout", out, g[f"{variant}.rollout_sl0"])
 
 
+@pytest.mark.parametrize("variant", ["ours", "lrp"])
+def test_vit_tiny_other_methods(golden_vit_tiny, golden_methods, variant):
+    """method="full" (position-embedding Add + Conv2d z^B rule through the MODE-3 C-pass kernel) and the
+    attention-only branches, vs the reference's own outputs."""
+    from transformer_explainability_amd import rules, rules_lrp, vit
+    from transformer_explainability_amd.generators import LRP
+    g, gm = golden_vit_tiny, golden_methods
+    ns = vit.make_vit_module(rules if variant == "ours" else rules_lrp)
+    model = ns["VisionTransformer"](img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10,
+                                    qkv_bias=True).eval()
+    model.load_state_dict(_state(g))
+    model.to(dev())
+    x = g["x"].to(dev())
+    lrp = LRP(model)
+    full = lrp.generate_LRP(x, method="full")
+    assert full.shape == (2, 32, 32)
+    check(f"vit_tiny.{variant}.full", full, gm[f"{variant}.full"], 2e-3)
+    # same cache through the oracle (tight): block stack -> position-embedding Add -> z^B rule
+    cache = vit_cache_from_model(model)
+    oh = _one_hot_of(model.head.Y.detach().cpu())
+    ref = O.vit_relprop(oh, cache, num_heads=4, variant=variant)
+    check(f"vit_tiny.{variant}.full.same_cache", full, O.vit_full_tail(ref["cam"], cache, variant), 2e-4)
+    for method, key in (("second_layer", "second_layer"), ("last_layer_attn", "last_layer_attn")):
+        out = lrp.generate_LRP(x, method=method)
+        check(f"vit_tiny.{variant}.{method}", out.reshape(2, -1), gm[f"{variant}.{key}"], 1e-3)
+    out = lrp.generate_LRP(x, method="last_layer", is_ablation=True)
+    check(f"vit_tiny.{variant}.ablation", out.reshape(2, -1), gm[f"{variant}.last_layer_ablation"], 1e-3)
+    out = lrp.generate_LRP(x, method="rollout", start_layer=1)
+    check(f"vit_tiny.{variant}.rollout_sl1", out, gm[f"{variant}.rollout_sl1"], 1e-3)
+
+
+def test_vit_b16_full_batch_equals_singles(vit_b16):
+    """method="full" at ViT-B/16 size: a batch of 4 equals 4 batch-1 runs on the same cached tensors (the z^B kernels
+    are per-sample by construction: min / max, S and the C-pass tiles never mix rows of different samples)."""
+    from transformer_explainability_amd.generators import LRP
+    from gpu_util import sliced_relprop_state
+    model = vit_b16.to(dev())
+    x = seeded_randn((4, 3, 224, 224), 5).to(dev())
+    lrp = LRP(model)
+    full = lrp.generate_LRP(x, method="full")
+    assert full.shape == (4, 224, 224) and torch.isfinite(full).all()
+    oh = _one_hot_of(model.head.Y.detach())
+    # relevance reaching the pixels: what is left of the unit relevance after the position embedding's and the class
+    # token's shares are dropped (ViT_LRP.py:338-339) -- recorded only
+    sums = full.double().sum(dim=(1, 2)).cpu()
+    record("vit_b16.full.pixel_relevance", sums=[float(v) for v in sums])
+    assert torch.isfinite(sums).all()
+    for i in range(4):
+        with sliced_relprop_state(model, i, 4):
+            one = model.relprop(oh[i:i + 1], method="full", alpha=1)
+        assert torch.equal(one[0], full[i]), i
+
+
+def test_baselines_against_reference(golden_methods):
+    from transformer_explainability_amd import vit
+    from transformer_explainability_amd.generators import Baselines
+    gm = golden_methods
+    m = vit.VisionTransformer(img_size=224, patch_size=16, embed_dim=64, depth=2, num_heads=4, num_classes=10,
+                              qkv_bias=True, block_norm_eps=1e-5, final_norm_eps=1e-5).eval()
+    m.load_state_dict(_state(gm, "baselines.state."), strict=True)
+    m.to(dev())
+    x = seeded_randn((2, 3, 224, 224), 2).to(dev())
+    b = Baselines(m)
+    check("baselines.cam_attn", b.generate_cam_attn(x), gm["baselines.cam_attn"], 1e-3)
+    for sl in (0, 1):
+        check(f"baselines.rollout_sl{sl}", b.generate_rollout(x, start_layer=sl), gm[f"baselines.rollout_sl{sl}"], 1e-5)
+
+
 def test_generate_visualization_api(golden_vit_tiny):
     """The notebooks' generate_visualization helper: [3,H,W] image -> uint8 [H,W,3] overlay (API surface)."""
     from transformer_explainability_amd import vit
@@ -80,7 +148,7 @@ def test_generate_visualization_api(golden_vit_tiny):
     assert vis.shape == (32, 32, 3) and vis.dtype.name == "uint8" and vis.max() == 255
 
 
-def test_baselines_rollout(golden_vit_tiny):
+def test_baselines_rollout_vs_oracle(golden_vit_tiny):
     """Baselines.generate_rollout (ViT_explanation_generator.py:74-83): head-averaged attention through the
     row-normalised rollout kernel vs the oracle's rollout on the same attention maps."""
     from transformer_explainability_amd import vit
@@ -161,6 +229,29 @@ def test_bert_tiny_golden(golden_bert_tiny):
     cam = model.relprop(oh, alpha=1)
     check("bert_tiny.cam_tokens", cam, g["cam_tokens"], 1e-3)
     assert abs(float(cam.double().sum()) - 1.0) < 1e-4
+
+
+def test_bert_tiny_other_methods(golden_bert_tiny, golden_methods):
+    """ExplanationGenerator.py:62-155, batched, vs the reference's per-sample outputs."""
+    from transformer_explainability_amd import bert
+    from transformer_explainability_amd.generators import Generator
+    g, gm = golden_bert_tiny, golden_methods
+    cfg = bert.BertConfigLite(vocab_size=100, hidden_size=64, num_hidden_layers=3, num_attention_heads=4,
+                              intermediate_size=128, max_position_embeddings=40, num_labels=2)
+    model = bert.BertForSequenceClassification(cfg).eval()
+    model.load_state_dict(_state(g))
+    model.to(dev())
+    ids, mask = g["input_ids"].long().to(dev()), g["attention_mask"].to(dev())
+    gen = Generator(model)
+    check("bert_tiny.last_layer", gen.generate_LRP_last_layer(ids, mask), gm["bert.last_layer"], 1e-3)
+    check("bert_tiny.full_lrp", gen.generate_full_lrp(ids, mask), gm["bert.full_lrp"], 1e-3)
+    check("bert_tiny.attn_last_layer", gen.generate_attn_last_layer(ids, mask), gm["bert.attn_last_layer"], 1e-5)
+    for sl in (0, 1):
+        check(f"bert_tiny.rollout_sl{sl}", gen.generate_rollout(ids, mask, start_layer=sl), gm[f"bert.rollout_sl{sl}"],
+              1e-5)
+    got, ref = gen.generate_attn_gradcam(ids, mask).cpu(), gm["bert.attn_gradcam"]
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))       # an all-clamped map is 0/0 in the reference too
+    check("bert_tiny.attn_gradcam", torch.nan_to_num(got), torch.nan_to_num(ref), 1e-3)
 
 
 # ------------------------------------------------------------------------------------------ ViT-B/16 full size

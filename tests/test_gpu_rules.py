@@ -392,3 +392,42 @@ def test_heatmap_consumer(B, g, scale, normalise):
     disagree = (mask.cpu() != ref_m)
     near = (ref_h - ref_h.reshape(B, -1).mean(1).reshape(B, 1, 1, 1)).abs() <= 1e-6 * ref_h.abs().max()
     assert not (disagree & ~near).any()
+
+
+# ------------------------------------------------------------------------------------------ Conv2d z^B (8f.3)
+@pytest.mark.parametrize("simple", [False, True], ids=["tiled", "simple"])
+@pytest.mark.parametrize("geom", [(2, 8, 12, 4, 12), (3, 32, 32, 8, 64), (2, 224, 224, 16, 768), (1, 48, 32, 16, 20)],
+                         ids=lambda g: "B%d_%dx%d_p%d_E%d" % g)
+def test_conv2d_zb(geom, simple):
+    """z^B rule of a patch convolution vs the oracle's three convolutions + three transposed convolutions, R handed
+    over as the token-major VIEW cam[:, 1:] that PatchEmbed.relprop builds (batch stride (P+1) E)."""
+    from transformer_explainability_amd import ops
+    set_impl(simple)
+    B, H, W, p, E = geom
+    X = rnd((B, 3, H, W), 71)
+    Wt, bias = rnd((E, 3, p, p), 72, 0.05), rnd((E,), 73, 0.1)
+    Hp, Wp = H // p, W // p
+    cam = rnd((B, Hp * Wp + 1, E), 74, 0.01)                       # [B, N, E] with the class token in front
+    R_view = cam[:, 1:].unflatten(1, (Hp, Wp)).permute(0, 3, 1, 2)  # [B,E,Hp,Wp], token-major memory
+    Y = torch.nn.functional.conv2d(X, Wt, bias, stride=p)
+    ref = O.conv2d_zb_relprop(R_view.contiguous(), X, Wt, p)
+    ref64 = O.conv2d_zb_relprop(R_view.contiguous().double(), X.double(), Wt.double(), p)
+    d = dev()
+    got = ops.conv2d_zb_relprop(cam.to(d)[:, 1:].unflatten(1, (Hp, Wp)).permute(0, 3, 1, 2), X.to(d), Wt.to(d), Y.to(d),
+                                bias.to(d))
+    check_conditioned(f"conv2d_zb{geom}{'simple' if simple else ''}", got, ref, ref64, 2e-6)
+    # an NCHW-contiguous R (what the reference's transpose + reshape produces) takes the copy path: same result
+    got2 = ops.conv2d_zb_relprop(R_view.contiguous().to(d), X.to(d), Wt.to(d), Y.to(d), bias.to(d))
+    assert torch.equal(got, got2)
+    # conservation of the z^B rule: sum(out) = sum(R * (Za - 1e-9) / Za) ~ sum(R)
+    assert abs(float(got.double().sum()) - float(R_view.double().sum())) <= 1e-4 * float(R_view.abs().double().sum())
+
+
+@pytest.mark.parametrize("variant", ["ours", "lrp"])
+def test_conv2d_zb_golden(golden_methods, variant):
+    from transformer_explainability_amd import ops
+    g, d = golden_methods, dev()
+    X, Wt, b, R = (g[f"conv_{variant}.{k}"] for k in ("X", "W", "b", "R"))
+    Y = torch.nn.functional.conv2d(X, Wt, b, stride=4)
+    got = ops.conv2d_zb_relprop(R.to(d), X.to(d), Wt.to(d), Y.to(d), b.to(d))
+    check(f"conv2d_zb.golden.{variant}", got, g[f"conv_{variant}.out"], 1e-5)

@@ -103,3 +103,26 @@ def test_safe_divide_branches():
     assert out[1] == 1.0 / 1e-9 or torch.isfinite(out[1])   # den == 0 -> 1e-9 replacement
     assert out[2] == 1.0 / (2.0 + 1e-9) or abs(float(out[2]) - 0.5) < 1e-6
     assert abs(float(out[3]) + 0.5) < 1e-6
+
+
+# ---- Conv2d z^B rule and method="full"
+@pytest.mark.parametrize("variant", ["ours", "lrp"])
+def test_conv2d_zb(golden_methods, variant):
+    g = golden_methods
+    out = O.conv2d_zb_relprop(g[f"conv_{variant}.R"], g[f"conv_{variant}.X"], g[f"conv_{variant}.W"], 4)
+    _close(out, g[f"conv_{variant}.out"])
+
+
+def test_vit_tiny_full_tail(golden_vit_tiny, golden_methods):
+    """oracle block stack (pinned above) -> position-embedding Add -> z^B rule -> channel sum == the reference's
+    method="full" map of sample 0."""
+    g = golden_vit_tiny
+    cache = unflatten_cache(g, "ours.cache.")
+    state = {k[len("state."):]: v for k, v in g.items() if k.startswith("state.")}
+    x = g["x"][:1]
+    p = state["patch_embed.proj.weight"].shape[-1]
+    tokens = torch.nn.functional.conv2d(x, state["patch_embed.proj.weight"], state["patch_embed.proj.bias"], stride=p)
+    tokens = torch.cat([state["cls_token"], tokens.flatten(2).transpose(1, 2)], dim=1)
+    cache.update(pos_add_x0=tokens, pos_embed=state["pos_embed"], patch_x=x, patch_w=state["patch_embed.proj.weight"])
+    full = O.vit_full_tail(g["ours.cam_tokens"], cache)
+    _close(full, golden_methods["ours.full"][:1], rel=1e-5)

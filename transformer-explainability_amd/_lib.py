@@ -53,6 +53,11 @@ SIGNATURES = {
     "te_index_select_relprop_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "te_gradcam_headmean_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "te_heatmap_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
+    "te_conv2d_zb_relprop_workspace_bytes": (_SZ, [_I64] * 6),
+    "te_conv2d_zb_relprop_f32": (_I, [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P, _SZ,
+                                      _P]),
+    "te_perturb_workspace_bytes": (_SZ, [_I64, _I64]),
+    "te_perturb_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _SZ, _P]),
     "te_rollout_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_rollout_f32": (_I, [_P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
 }

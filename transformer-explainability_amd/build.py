@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libte_relprop.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 
 SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_attn.hip", "te_attn_mfma.hip",
-           "te_rollout.hip", "te_heatmap.hip"]
+           "te_rollout.hip", "te_heatmap.hip", "te_conv.hip", "te_perturb.hip"]
 
 CXXFLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

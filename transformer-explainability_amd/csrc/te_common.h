@@ -59,6 +59,22 @@ __device__ __forceinline__ void te_block_sum3(double& a, double& b, double& c, d
   }
 }
 
+// Patch geometry of a stride == kernel convolution (ViT patch embedding): row t = (b, py, px) of the im2col matrix,
+// column k = (c, dy, dx); te_zb_index maps (t, k) to the element's offset in the NCHW image.
+struct TeZbGeom {
+  const float* lohi;    // [B][2] per-sample pixel min / max
+  int64_t P;            // patches per sample = Hp * Wp
+  int C, H, W, p, Wp;
+};
+__host__ __device__ __forceinline__ int64_t te_zb_index(const TeZbGeom& g, int64_t t, int64_t k) {
+  const int64_t b = t / g.P;
+  const int tl = (int)(t - b * g.P), py = tl / g.Wp, px = tl - py * g.Wp;
+  const int pp = g.p * g.p, c = (int)(k / pp), rem = (int)(k - (int64_t)c * pp), dy = rem / g.p, dx = rem - dy * g.p;
+  return ((b * g.C + c) * g.H + (int64_t)py * g.p + dy) * g.W + (int64_t)px * g.p + dx;
+}
+bool te_internal_zb_cpass_tiled(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
+                                int64_t out_f, const TeZbGeom& zb, hipStream_t stream);
+
 static inline bool te_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int64_t te_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t te_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

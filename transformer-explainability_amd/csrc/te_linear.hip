@@ -365,11 +365,14 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 //     MODE 1: out  = scale * X+ . (S W(+))   (lrp first half, S = S1)
 //     MODE 2: out += scale * X- . (S W(-))   (lrp second half, S = S2)
 //     SWAP exchanges W+ / W-.  ACCUM: out = out - scale * (...)   (the beta * inhibitor term)
+//     MODE 3: z^B rule of the patch-embedding convolution (Conv2d.relprop, layers_ours.py:242-256): same two
+//             products P = S W+, N = S W-, epilogue out = x (P + N) - l_b P - h_b N with x read from / out written
+//             to the NCHW image through the patch geometry (no im2col copy); l_b, h_b = sample b's pixel min / max
 // ------------------------------------------------------------------------------------------------
 template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
 __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
     const float* __restrict__ S, const float* __restrict__ W, const float* __restrict__ X,
-    float* __restrict__ out, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles, float scale) {
+    float* __restrict__ out, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles, float scale, TeZbGeom zb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MI = BM / 64, NI = BN / 64, WM = BM / 2, WN = BN / 2;
   constexpr int A_SZ = BM * LDT, B_SZ = BK * BN;
@@ -382,7 +385,8 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
   const int nk = (int)((K + BK - 1) / BK);
   const bool interior = (tc.row0 + BM <= T) && (tc.col0 + BN <= Nn) && (K % BK == 0);   // block-uniform
 
-  constexpr int NACC = (MODE == 0) ? 2 : 1;
+  constexpr bool BOTH = (MODE == 0 || MODE == 3);
+  constexpr int NACC = BOTH ? 2 : 1;
   f32x16 acc[NACC][MI][NI];
 #pragma unroll
   for (int s = 0; s < NACC; ++s)
@@ -418,13 +422,13 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
         bp[ni] = SWAP ? n : p;
         bn[ni] = SWAP ? p : n;
       }
-      if constexpr (MODE == 0 || MODE == 1) {
+      if constexpr (BOTH || MODE == 1) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) acc[0][mi][ni] = TE_MFMA(f.a[mi][j], bp[ni], acc[0][mi][ni]);
       }
-      if constexpr (MODE == 0 || MODE == 2) {
+      if constexpr (BOTH || MODE == 2) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -487,7 +491,14 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (gr < T && gc < Nn) {
+        if constexpr (MODE == 3) {
+          if (gr < T && gc < Nn) {
+            const int64_t b = gr / zb.P;
+            const int64_t at = te_zb_index(zb, gr, gc);
+            const float Pp = acc[0][mi][ni][e], Pn = acc[1][mi][ni][e];
+            out[at] = (X[at] * (Pp + Pn) - zb.lohi[2 * b] * Pp) - zb.lohi[2 * b + 1] * Pn;
+          }
+        } else if (gr < T && gc < Nn) {
           const float x = X[gr * Nn + gc];
           const float xp = fmaxf(x, 0.0f), xn = fminf(x, 0.0f);
           float val;
@@ -606,13 +617,13 @@ inline void launch_k1(const float* X, const float* W, const float* R, const floa
 }
 template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
 inline void launch_k2(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
-                      int64_t out_f, float scale, hipStream_t stream) {
+                      int64_t out_f, float scale, hipStream_t stream, TeZbGeom zb = TeZbGeom{}) {
   const int nbn = (int)te_ceil_div(in_f, BN);
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k2_lds<BM, BN>();
   allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN>, lds);
   linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
-      S, W, X, out, T, out_f, in_f, nbn, ntiles, scale);
+      S, W, X, out, T, out_f, in_f, nbn, ntiles, scale, zb);
 }
 
 #define TE_DISPATCH_TILE(tile, CALL)                  \
@@ -662,6 +673,17 @@ int run_half(const float* R, const float* X, const float* W, float* out, int64_t
 }
 
 }  // namespace
+
+// C-pass of the z^B rule (te_conv.hip): MODE 3 epilogue on the same tiled kernel; false when the shape needs the
+// simple kernel there
+bool te_internal_zb_cpass_tiled(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
+                                int64_t out_f, const TeZbGeom& zb, hipStream_t stream) {
+  if ((in_f % 4) || (out_f % 4) || !te_aligned16(S) || !te_aligned16(W)) return false;
+#define TE_K2(BM_, BN_) launch_k2<3, false, false, BM_, BN_>(S, W, X, out, T, in_f, out_f, 1.0f, stream, zb)
+  TE_DISPATCH_TILE(pick_tile(T, in_f), TE_K2);
+#undef TE_K2
+  return true;
+}
 
 // ---- single-pass entry points (variant "ours", alpha = 1): the two kernels of te_linear_relprop_f32
 // individually, so that a caller can bracket ONE kernel launch with events (bench.py roofline) or

@@ -238,3 +238,48 @@ class Generator:
         cam = layers[-1].attention.self.get_attn_cam().clamp(min=0).mean(dim=1)[:, 0].clone()
         cam[:, 0] = 0
         return cam
+
+    def generate_full_lrp(self, input_ids, attention_mask, index=None):
+        """ExplanationGenerator.py:86-106: relevance propagated to the encoder input, summed over the hidden
+        dimension, CLS slot zeroed."""
+        output = self.model(input_ids=input_ids, attention_mask=attention_mask)[0]
+        one_hot = _one_hot(output, index)
+        layers = self.model.bert.encoder.layer
+        # relprop reads the attention gradients nowhere, but the reference runs the backward first (:100-101) and the
+        # accessors are part of the boundary: keep them populated
+        _attention_gradients(torch.sum(one_hot * output), [lay.attention.self for lay in layers])
+        cam = self.model.relprop(one_hot, alpha=1).sum(dim=2)
+        cam[:, 0] = 0
+        return cam
+
+    def generate_attn_last_layer(self, input_ids, attention_mask, index=None):
+        """ExplanationGenerator.py:108-114: head-mean of the last layer's attention probabilities, CLS row."""
+        with torch.no_grad():
+            self.model(input_ids=input_ids, attention_mask=attention_mask)
+            cam = self.model.bert.encoder.layer[-1].attention.self.get_attn().mean(dim=1)[:, 0].clone()
+        cam[:, 0] = 0
+        return cam
+
+    def generate_rollout(self, input_ids, attention_mask, start_layer=0, index=None):
+        """ExplanationGenerator.py:116-127: row-normalised rollout of the head-averaged attention probabilities."""
+        with torch.no_grad():
+            self.model(input_ids=input_ids, attention_mask=attention_mask)
+            mats = [lay.attention.self.get_attn().mean(dim=1) for lay in self.model.bert.encoder.layer]
+            joint = ops.rollout(torch.stack(mats, 0), start_layer=start_layer, normalise=True)
+        out = joint[:, 0].clone()
+        out[:, 0] = 0
+        return out
+
+    def generate_attn_gradcam(self, input_ids, attention_mask, index=None):
+        """ExplanationGenerator.py:129-155: last layer's attention x its per-head mean gradient, head-mean, clamped,
+        min-max normalised over the whole [N, N] map, CLS row with the CLS slot zeroed."""
+        layers = self._explain(input_ids, attention_mask, index)
+        sa = layers[-1].attention.self
+        cam = sa.get_attn().detach()
+        grad = sa.get_attn_gradients().mean(dim=[2, 3], keepdim=True)
+        cam = (cam * grad).mean(dim=1).clamp(min=0)
+        lo = cam.amin(dim=(1, 2), keepdim=True)
+        hi = cam.amax(dim=(1, 2), keepdim=True)
+        cam = ((cam - lo) / (hi - lo))[:, 0].clone()
+        cam[:, 0] = 0
+        return cam

@@ -291,6 +291,36 @@ def rollout(cams: Tensor, start_layer: int = 0, normalise: bool = False, cls_fix
     return joint
 
 
+# ---------------------------------------------------------------------------------------- 8f.3 Conv2d z^B
+def conv2d_zb_relprop(R: Tensor, X: Tensor, W: Tensor, Y: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """Conv2d.relprop, z^B rule (layers_ours.py:242-256), for a stride == kernel, padding 0 convolution (the ViT patch
+    embedding).  R [B,E,Hp,Wp] with any strides (the token-major view PatchEmbed.relprop builds is consumed in
+    place), X [B,C,H,W], W [E,C,p,p], Y = the layer's forward output [B,E,Hp,Wp] -> relevance [B,C,H,W]."""
+    B, C, H, Wd = X.shape
+    E, p = W.shape[0], W.shape[2]
+    if W.shape[1] != C or W.shape[3] != p or H % p or Wd % p:
+        raise _lib.TeError(f"conv2d_zb_relprop: not a patch convolution: X {tuple(X.shape)}, W {tuple(W.shape)}")
+    Hp, Wp = H // p, Wd // p
+    P = Hp * Wp
+    if tuple(R.shape) != (B, E, Hp, Wp) or tuple(Y.shape) != (B, E, Hp, Wp):
+        raise _lib.TeError(f"conv2d_zb_relprop: R {tuple(R.shape)} / Y {tuple(Y.shape)} do not match [B,E,H/p,W/p]")
+    Rt = R.permute(0, 2, 3, 1)                       # [B,Hp,Wp,E]
+    st = Rt.stride()
+    if R.dtype != torch.float32 or not (st[3] == 1 and st[2] == E and st[1] == Wp * E and st[0] >= P * E
+                                        and R.data_ptr() % 16 == 0):
+        Rt = Rt.float().contiguous()
+        st = Rt.stride()
+    X, W, Y = _c(X), _c(W), _c(Y)
+    bias = None if bias is None else _c(bias)
+    out = torch.empty_like(X)
+    with _on_device(X) as lib:
+        ws = _ws(lib.te_conv2d_zb_relprop_workspace_bytes(B, C, H, Wd, E, p), X)
+        _lib.check(lib.te_conv2d_zb_relprop_f32(_ptr(Rt), st[0], _ptr(X), _ptr(W), _ptr(Y), _ptr(bias), _ptr(out), B, C,
+                                                H, Wd, E, p, TE_IMPL_SIMPLE if FORCE_SIMPLE else 0, _ptr(ws),
+                                                ws.numel(), _stream(X)), "te_conv2d_zb_relprop_f32")
+    return out
+
+
 # ---------------------------------------------------------------------------------------- 8f.2 consumer
 def heatmap(maps: Tensor, scale: int = 16, normalise: bool = True, with_mask: bool = False):
     """maps [B, g*g] or [B,1,g,g] -> heat [B,1,g*scale,g*scale]: bilinear up-sampling + per-map min-max
@@ -307,3 +337,28 @@ def heatmap(maps: Tensor, scale: int = 16, normalise: bool = True, with_mask: bo
         _lib.check(lib.te_heatmap_f32(_ptr(m), _ptr(heat), _ptr(mask), B, g, int(scale), int(bool(normalise)), _stream(m)),
                    "te_heatmap_f32")
     return (heat, mask) if with_mask else heat
+
+
+# ---------------------------------------------------------------------------------------- 8f.4 perturbation inputs
+def perturb(vis: Tensor, data: Tensor, ks: Sequence[int], mean: Optional[Sequence[float]] = None,
+            std: Optional[Sequence[float]] = None) -> Tensor:
+    """pertubation_eval_from_hdf5.py:88-101 for all steps at once: vis [B, H*W] (or [B,1,H,W]) relevance, data
+    [B,C,H,W] -> [len(ks), B, C, H, W]: the ks[s] most relevant pixels of every sample zeroed in every channel, then
+    (x - mean[c]) / std[c]."""
+    import ctypes
+    data = _c(data)
+    B, C, H, W = data.shape
+    HW = H * W
+    vis = _c(vis).reshape(B, -1)
+    if vis.shape[1] != HW:
+        raise _lib.TeError(f"perturb: vis {tuple(vis.shape)} does not cover the {H}x{W} pixels of data")
+    S = len(ks)
+    out = torch.empty((S, B, C, H, W), dtype=torch.float32, device=data.device)
+    k_arr = (ctypes.c_int64 * S)(*[int(k) for k in ks])
+    m_arr = None if mean is None else (ctypes.c_float * C)(*[float(v) for v in mean])
+    s_arr = None if std is None else (ctypes.c_float * C)(*[float(v) for v in std])
+    with _on_device(data) as lib:
+        ws = _ws(lib.te_perturb_workspace_bytes(B, S), data)
+        _lib.check(lib.te_perturb_f32(_ptr(vis), _ptr(data), _ptr(out), B, C, HW, k_arr, S, m_arr, s_arr, _ptr(ws),
+                                      ws.numel(), _stream(data)), "te_perturb_f32")
+    return out

@@ -232,5 +232,16 @@ class BatchNorm2d(nn.BatchNorm2d, _OffPath):
     pass
 
 
-class Conv2d(nn.Conv2d, _OffPath):
-    pass
+class Conv2d(nn.Conv2d, RelProp):
+    """layers_ours.py:232-279.  Accelerated: the z^B rule of an image-input (3-channel) convolution whose stride
+    equals its kernel with no padding -- the ViT patch embedding, reached by method="full" (ViT_LRP.py:337-343) ->
+    te_conv2d_zb_relprop_f32.  Other geometries are off the transformer path."""
+
+    def relprop(self, R, alpha):
+        k = self.kernel_size
+        patch = (self.X.shape[1] == 3 and k[0] == k[1] and tuple(self.stride) == tuple(k)
+                 and tuple(self.padding) == (0, 0) and tuple(self.dilation) == (1, 1) and self.groups == 1)
+        if not patch:
+            raise NotImplementedError("Conv2d.relprop: only the z^B rule of a patch-embedding convolution "
+                                      "(3 input channels, stride == kernel, no padding) is accelerated")
+        return ops.conv2d_zb_relprop(R, self.X, self.weight, self.Y, self.bias)

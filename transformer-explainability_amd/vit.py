@@ -122,11 +122,11 @@ def make_vit_module(L):
             return self.qkv.relprop(cam_qkv, **kwargs)
 
     class Block(nn.Module):
-        def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0.):
+        def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., norm_eps=1e-6):
             super().__init__()
-            self.norm1 = L.LayerNorm(dim, eps=1e-6)
+            self.norm1 = L.LayerNorm(dim, eps=norm_eps)
             self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
-            self.norm2 = L.LayerNorm(dim, eps=1e-6)
+            self.norm2 = L.LayerNorm(dim, eps=norm_eps)
             self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
             self.add1 = L.Add()
             self.add2 = L.Add()
@@ -188,16 +188,18 @@ def make_vit_module(L):
             return self.proj(x).flatten(2).transpose(1, 2)
 
         def relprop(self, cam, **kwargs):
-            cam = cam.transpose(1, 2)
-            cam = cam.reshape(cam.shape[0], cam.shape[1], self.img_size[0] // self.patch_size[0],
-                              self.img_size[1] // self.patch_size[1])
-            return self.proj.relprop(cam, **kwargs)
+            # ViT_LRP.py:238-242: [B,P,E] -> [B,E,Hp,Wp]; built as a VIEW so the kernel reads the token-major memory
+            # in place (the reference's transpose + reshape copies)
+            cam = cam.unflatten(1, (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1]))
+            return self.proj.relprop(cam.permute(0, 3, 1, 2), **kwargs)
 
     class VisionTransformer(nn.Module):
         default_method = "transformer_attribution" if L.RelProp.variant == "ours" else "grad"
 
         def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
-                     num_heads=12, mlp_ratio=4., qkv_bias=False, mlp_head=False, drop_rate=0., attn_drop_rate=0.):
+                     num_heads=12, mlp_ratio=4., qkv_bias=False, mlp_head=False, drop_rate=0., attn_drop_rate=0.,
+                     block_norm_eps=1e-6, final_norm_eps=1e-5):
+            # (the LayerNorm epsilons are ViT_LRP.py:184,187,266; ViT_new.py uses other values -- see the drop-in)
             super().__init__()
             self.num_classes = num_classes
             self.num_features = self.embed_dim = embed_dim
@@ -208,8 +210,8 @@ def make_vit_module(L):
             self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
             self.blocks = nn.ModuleList([
                 Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
-                      attn_drop=attn_drop_rate) for _ in range(depth)])
-            self.norm = L.LayerNorm(embed_dim)
+                      attn_drop=attn_drop_rate, norm_eps=block_norm_eps) for _ in range(depth)])
+            self.norm = L.LayerNorm(embed_dim, eps=final_norm_eps)
             self.head = Mlp(embed_dim, int(embed_dim * mlp_ratio), num_classes) if mlp_head \
                 else L.Linear(embed_dim, num_classes)
             _trunc_normal_(self.pos_embed, std=.02)
@@ -270,7 +272,11 @@ def make_vit_module(L):
                 cam = blk.relprop(cam, **kwargs)
 
             if method == "full":
-                raise NotImplementedError("method='full' (Conv2d z^B rule) is off the accelerated hot path")
+                # ViT_LRP.py:337-343: position-embedding Add, drop the class token, z^B rule of the patch
+                # embedding, sum over the colour channels -> [B, H, W]
+                cam, _ = self.add.relprop(cam, **kwargs)
+                cam = self.patch_embed.relprop(cam[:, 1:], **kwargs)
+                return cam.sum(dim=1)
 
             if method == "rollout":
                 mats = [blk.attn.get_attn_cam().clamp(min=0).mean(dim=1) for blk in self.blocks]
