@@ -42,6 +42,14 @@ def check(name, got, ref, rel_tol, exact=False):
     return s
 
 
+def check_nan_aware(name, got, ref, rel_tol):
+    """check() for outputs where the reference itself yields NaN (0/0 of an all-clamped map): the NaN positions must
+    agree, the rest is compared as usual."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)), name
+    return check(name, torch.nan_to_num(got), torch.nan_to_num(ref), rel_tol)
+
+
 def check_conditioned(name, got, ref32, ref64, base_tol, k=20.0):
     """Conditioning-aware comparison for rules that divide by a mixed-sign sum (safe_divide(R, Z) with
     Z = sum of products of either sign): the fp32 oracle itself is only accurate to its own distance
