@@ -72,7 +72,14 @@ def perturb(vis, data, ks, mean=None, std=None):
     return O.perturb(vis.reshape(data.shape[0], -1), data, ks, mean, std)
 
 
-_NAMES = ["perturb", "conv2d_zb_relprop", "linear_relprop", "matmul_relprop_av", "matmul_relprop_qk", "add_relprop", "clone_relprop",
+def heatmap(maps, scale=16, normalise=True, with_mask=False):
+    B = maps.shape[0]
+    g = int(round((maps.numel() // B) ** 0.5))
+    heat, mask = O.heatmap(maps.reshape(B, g * g), scale=scale, normalise=normalise)
+    return (heat, mask) if with_mask else heat
+
+
+_NAMES = ["heatmap", "perturb", "conv2d_zb_relprop", "linear_relprop", "matmul_relprop_av", "matmul_relprop_qk", "add_relprop", "clone_relprop",
           "index_select_relprop", "gradcam_headmean", "rollout"]
 
 

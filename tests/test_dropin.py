@@ -20,6 +20,7 @@ from BERT_explainability.modules.BERT.ExplanationGenerator import Generator     
 from BERT_explainability.modules.BERT.BertForSequenceClassification import BertForSequenceClassification
 from BERT_explainability.modules.BERT.BERT import BertModel
 from BERT_explainability.modules.layers_ours import Linear as BL, MatMul, Tanh
+from dataset.expl_hdf5 import ImagenetResults                            # pertubation_eval_from_hdf5.py:13
 import modules.layers_ours as lo, modules.layers_lrp as ll
 assert lo.Linear.variant == "ours" and ll.Linear.variant == "lrp"
 for name in ['forward_hook', 'Clone', 'Add', 'Cat', 'ReLU', 'GELU', 'Dropout', 'BatchNorm2d', 'Linear', 'MaxPool2d',

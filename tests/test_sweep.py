@@ -1,0 +1,105 @@
+"""the saliency sweep and its result store (generate_visualizations.py:27-100,
+dataset/expl_hdf5.py:8-31), on CPU with the device ops routed to the oracle; `-m gpu`: the same sweep on the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+CFG = dict(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10, qkv_bias=True)
+
+
+class ToyImages(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(100 + i)
+        return torch.rand((3, 32, 32), generator=g), i % 10
+
+
+def _generators(device):
+    from transformer_explainability_amd import rules_lrp, vit
+    from transformer_explainability_amd.generators import LRP, Baselines
+    torch.manual_seed(0)
+    model = vit.VisionTransformer(**CFG).eval().to(device)
+    orig = vit.make_vit_module(rules_lrp)["VisionTransformer"](**CFG).eval()
+    orig.load_state_dict(model.state_dict())
+    return LRP(model), LRP(orig.to(device)), Baselines(model)
+
+
+def _sweep(method, device, tmp, world=1, backend="npy", vis_class="top"):
+    from transformer_explainability_amd.sweep import ResultsStore, SaliencySweep, shard_batches
+    lrp, orig, base = _generators(device)
+    ds = ToyImages(7)
+    sw = SaliencySweep(method, lrp=lrp, orig_lrp=orig, baselines=base, vis_class=vis_class, device=device)
+    for rank in range(world):                       # (sequentially here; tests/test_parallel_gloo.py covers processes)
+        batches, lo, hi = shard_batches(ds, 3, rank, world)
+        with ResultsStore(tmp, len(ds), (3, 32, 32), (1, 32, 32), lo, hi, backend=backend) as store:
+            sw.run(batches, store, rank, world)
+    return ds
+
+
+def _check_store(ds, path, method, device, vis_class="top"):
+    from transformer_explainability_amd.sweep import ImagenetResults, SaliencySweep, normalize
+    res = ImagenetResults(path)
+    assert len(res) == len(ds)
+    lrp, orig, base = _generators(device)
+    sw = SaliencySweep(method, lrp=lrp, orig_lrp=orig, baselines=base, vis_class=vis_class, device=device)
+    for i in (0, 3, 6, -1):
+        image, vis, target = res[i]
+        ref_img, ref_t = ds[i % len(ds)]
+        assert torch.equal(image, ref_img) and int(target) == ref_t and target.dtype == torch.int64
+        assert vis.shape == (1, 32, 32) and vis.dtype == torch.float32
+        one = sw.explain(normalize(ref_img[None].to(device)), torch.tensor([ref_t], device=device))[0].cpu()
+        assert float((vis - one).abs().max()) <= 2e-4, (method, i)      # batch-of-3 vs batch-of-1 forward rounding
+        assert float(vis.min()) == 0.0 and float(vis.max()) == 1.0
+    with pytest.raises(IndexError):
+        res[len(ds)]
+
+
+@pytest.mark.parametrize("method", ["transformer_attribution", "rollout", "lrp", "full_lrp", "lrp_last_layer",
+                                    "attn_last_layer", "attn_gradcam"])
+def test_sweep_methods_cpu(method, tmp_path):
+    from oracle_backend import oracle_ops
+    with oracle_ops():
+        ds = _sweep(method, torch.device("cpu"), str(tmp_path))
+        _check_store(ds, str(tmp_path), method, torch.device("cpu"))
+
+
+def test_sweep_sharded_equals_single(tmp_path):
+    """Two ranks writing their own shard files reproduce the single-rank store, in global order."""
+    from oracle_backend import oracle_ops
+    from transformer_explainability_amd.sweep import ImagenetResults
+    a, b = tmp_path / "one", tmp_path / "two"
+    with oracle_ops():
+        _sweep("transformer_attribution", torch.device("cpu"), str(a), world=1, vis_class="target")
+        _sweep("transformer_attribution", torch.device("cpu"), str(b), world=2, vis_class="target")
+    ra, rb = ImagenetResults(str(a)), ImagenetResults(str(b))
+    assert len(ra) == len(rb) == 7
+    for i in range(7):
+        for x, y in zip(ra[i], rb[i]):
+            assert x.shape == y.shape and float((x.float() - y.float()).abs().max()) <= 2e-4
+
+
+def test_store_guards(tmp_path):
+    from transformer_explainability_amd.sweep import ImagenetResults, ResultsStore, SaliencySweep
+    with pytest.raises(ValueError):
+        SaliencySweep("no_such_method")
+    with pytest.raises(FileNotFoundError):
+        ImagenetResults(str(tmp_path))
+    st = ResultsStore(str(tmp_path), 2, (3, 4, 4), (1, 4, 4), backend="npy")
+    st.append(torch.zeros(2, 3, 4, 4), torch.tensor([1, 2]), torch.zeros(2, 1, 4, 4))
+    with pytest.raises(ValueError):
+        st.append(torch.zeros(1, 3, 4, 4), torch.tensor([1]), torch.zeros(1, 1, 4, 4))
+    st.close()
+    assert np.load(str(tmp_path / "results" / "target.000000000-000000002.npy")).tolist() == [1, 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["transformer_attribution", "full_lrp", "attn_gradcam"])
+def test_sweep_gpu(method, tmp_path):
+    d = torch.device("cuda:0")
+    ds = _sweep(method, d, str(tmp_path), world=2)
+    _check_store(ds, str(tmp_path), method, d)
