@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--graph", choices=["on", "off"], default="on",
                     help="replay each step from a HIP graph (one eager step inside the timed region carries the "
                          "per-kernel HIP events of the roofline)")
+    ap.add_argument("--overlap-backward", choices=["on", "off"], default="off",
+                    help="run the relprop rules on a side stream beside the attention-gradient backward pass (they are "
+                         "independent until the head-mean / rollout tail); the roofline probe step stays serial")
     ap.add_argument("--inflight", type=int, default=1,
                     help="consecutive steps (batches) in flight, each on its own HIP stream: the forward/backward of "
                          "step k+1 overlaps the relprop of step k")
@@ -189,7 +192,7 @@ def main():
     model.to(dev)
     B = args.batch
     x = torch.stack([synthetic_image(rank * B + i) for i in range(B)]).to(dev)
-    lrp = LRP(model, streams=args.streams)
+    lrp = LRP(model, streams=args.streams, overlap_backward=(args.overlap_backward == "on"))
     log(f"rank {rank}/{world}: model + {B} images resident on {dev}")
 
     timer = KernelTimer()
@@ -215,6 +218,14 @@ def main():
     def step(eager=False):
         if graphed is not None and not eager:
             return graphed(x)
+        if eager and lrp.overlap_backward:
+            # the probe step times single launches with HIP events: run it serially so that a kernel's duration is
+            # its own (with the overlap, kernels of the two streams share the CUs)
+            lrp.overlap_backward = False
+            try:
+                return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
+            finally:
+                lrp.overlap_backward = True
         if lanes is None:
             return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
         # every tensor of a step is allocated, produced and consumed on that step's stream
@@ -274,6 +285,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": 197, "blocks": 12,
                        "start_layer": args.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "streams": args.streams, "steps_in_flight": args.inflight,
+                       "relprop_beside_backward": args.overlap_backward == "on",
                        "hip_graph": graphed is not None, "parallelism": f"dp{world} (independent samples, one "
                                                                       f"all_gather of the maps)"},
         }

@@ -18,6 +18,7 @@ and seeded ``randn`` inputs, torch CPU fp32.  Fixtures:
                   narrow 14x14-patch ViT_new; the other Generator methods on the tiny BERT (weights = bert_tiny.npz)
   perturbation.npz  SURVEY.md 8f.4: the six result arrays of pertubation_eval_from_hdf5.py's eval(args), run on a
                   narrow ViT_new and seeded inputs (positive / negative / fixed-pixel-count modes)
+  seg_metrics.npz   the reference's utils/metrices.py functions called as imagenet_seg_eval.py calls them
 """
 import os
 import sys
@@ -400,10 +401,46 @@ def make_perturbation():
     print("perturbation.npz", len(out), "arrays")
 
 
+# ------------------------------------------------------------------------------------------
+def segmentation_inputs():
+    """Seeded heat maps (quantised so that equal scores occur, as in the flat regions of a real map), thresholded
+    masks and labels for the segmentation-metric fixture."""
+    g = torch.Generator().manual_seed(9)
+    heat = (torch.rand((3, 32, 32), generator=g) * 50).round() / 50
+    heat[0, :4] = 0.5
+    mask = (heat > heat.flatten(1).mean(1).view(-1, 1, 1)).float()
+    labels = (torch.rand((3, 32, 32), generator=g) > 0.6).long()
+    labels[2, 5] = 0                                                     # an all-negative row (F1 = 0 there)
+    mask[2, 5] = 0
+    return heat, mask, labels
+
+
+def make_segmentation():
+    """The reference's own metric functions (utils/metrices.py) called as imagenet_seg_eval.py:229-268 calls them."""
+    with rh.reference_on_path():
+        import importlib
+        M = importlib.import_module("utils.metrices")
+    heat, mask, labels = segmentation_inputs()
+    out = {k: [] for k in ("correct", "labeled", "inter", "union", "ap", "f1")}
+    for b in range(heat.shape[0]):
+        Res, Res_1 = heat[b:b + 1].unsqueeze(0), mask[b:b + 1].unsqueeze(0)        # [1,1,H,W]
+        Res_0 = 1 - Res_1
+        output = torch.cat((Res_0, Res_1), 1)
+        output_AP = torch.cat((1 - Res, Res), 1)
+        lab = labels[b:b + 1]
+        c, l = M.batch_pix_accuracy(output[0], lab[0])
+        i, u = M.batch_intersection_union(output[0], lab[0], 2)
+        out["correct"].append(c), out["labeled"].append(l), out["inter"].append(i), out["union"].append(u)
+        out["ap"].append(np.nan_to_num(M.get_ap_scores(output_AP, lab))[0])
+        out["f1"].append(np.nan_to_num(M.get_f1_scores(output[0, 1], lab[0])))
+    np.savez_compressed(os.path.join(HERE, "seg_metrics.npz"), **{k: np.asarray(v) for k, v in out.items()})
+    print("seg_metrics.npz", {k: np.asarray(v).shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if not rh.reference_available():
         sys.exit("reference checkout not found at " + rh.REFERENCE_ROOT)
-    which = sys.argv[1:] or ["rules", "vit_tiny", "vit_b16", "bert_tiny", "bert_base", "methods", "perturbation"]
+    which = sys.argv[1:] or ["rules", "vit_tiny", "vit_b16", "bert_tiny", "bert_base", "methods", "perturbation", "segmentation"]
     if "rules" in which:
         make_rules()
     if "vit_tiny" in which:
@@ -418,3 +455,5 @@ if __name__ == "__main__":
         make_methods()
     if "perturbation" in which:
         make_perturbation()
+    if "segmentation" in which:
+        make_segmentation()

@@ -378,6 +378,14 @@ def test_vit_b16_batch_equals_singles(vit_b16):
     replayed = glrp(x2).clone()
     assert torch.equal(replayed, lrp.generate_LRP(x2, start_layer=1))
     del glrp
+    # relprop on a side stream beside the backward pass == the serial pass, bitwise; eager and replayed from a graph
+    lrp_ov = LRP(model, overlap_backward=True)
+    assert torch.equal(lrp_ov.generate_LRP(x, start_layer=1), batch)
+    assert torch.equal(lrp_ov.generate_LRP(x2, start_layer=1), replayed)
+    glrp = GraphedLRP(lrp_ov, x, method="transformer_attribution", start_layer=1)
+    assert torch.equal(glrp(x), batch)
+    assert torch.equal(glrp(x2), replayed)
+    del glrp
     singles = torch.cat([lrp.generate_LRP(x[i:i + 1], start_layer=1) for i in range(B)], 0)
     _assert_map("vit_b16.batch_vs_separate_forwards", batch, singles, **LOOSE)
     # LRP conservation: the token relevance of every sample sums to 1

@@ -192,7 +192,7 @@ __device__ __noinline__ float exact_z(const float* __restrict__ x, const float* 
   return z1 + z2;
 }
 
-template <int ZM, bool SWAP, int BM, int BN>
+template <int ZM, bool SWAP, int BM, int BN, int VAR = 0>
 __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ R,
     const float* __restrict__ Y, const float* __restrict__ bias,
@@ -297,6 +297,66 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
           for (int e = 0; e < 4; ++e) rb[i][e] = te_abs(rb[i][e]);
       }
     };
+    if constexpr (FWD && (VAR == 2)) {
+      // prefetch distance 2: two register stages; the loads of K-step kt+2 are issued right after the barrier that
+      // published step kt+1 and are consumed (abs + ds_write) at the end of step kt+1 -- two K-steps of MFMAs cover
+      // one global round trip instead of three quarters of one
+      f32x4 qa[BM / 32], qb[BN / 32];
+      auto load_into = [&](int kt, f32x4 (&xa)[BM / 32], f32x4 (&xb)[BN / 32]) __attribute__((always_inline)) {
+        if constexpr (FAST) {
+          load_rows_tile_fast<BM>(X, K, tc.row0, (int64_t)kt * BK, xa);
+          load_rows_tile_fast<BN>(W, K, tc.col0, (int64_t)kt * BK, xb);
+        } else {
+          load_rows_tile<BM>(X, T, K, tc.row0, (int64_t)kt * BK, xa);
+          load_rows_tile<BN>(W, Nn, K, tc.col0, (int64_t)kt * BK, xb);
+        }
+      };
+      auto abs_store = [&](int stage, f32x4 (&xa)[BM / 32], f32x4 (&xb)[BN / 32]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xa[i][e] = te_abs(xa[i][e]);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xb[i][e] = te_abs(xb[i][e]);
+        store_rows_tile<BM>(smem + stage * STAGE, xa);
+        store_rows_tile<BN>(smem + stage * STAGE + A_SZ, xb);
+      };
+      load_into(0, ra, rb);
+      abs_store(0, ra, rb);
+      __syncthreads();
+      if (nk > 1) load_into(1, ra, rb);       // ra/rb hold odd steps' successors alternately: see body()
+      if (nk > 2) load_into(2, qa, qb);
+      Frag f0, f1;
+      read_frag(f0, 0, 0);
+      // body(kt, cur, nxt regs = the set holding step kt+1): compute stage cur, publish kt+1, refill the set with kt+3
+      auto body = [&](int kt, int cur, f32x4 (&xa)[BM / 32], f32x4 (&xb)[BN / 32]) __attribute__((always_inline)) {
+        const bool more = kt + 1 < nk;
+        read_frag(f1, cur, 1);
+        mma_group(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f0, cur, 2);
+        mma_group(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f1, cur, 3);
+        mma_group(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          abs_store(cur ^ 1, xa, xb);
+          __syncthreads();
+          if (kt + 3 < nk) load_into(kt + 3, xa, xb);
+          read_frag(f0, cur ^ 1, 0);
+        }
+        mma_group(f1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int kt = 0; kt < nk; kt += 2) {
+        body(kt, 0, ra, rb);
+        if (kt + 1 < nk) body(kt + 1, 1, qa, qb);
+      }
+      return;
+    }
     load_next(0);
     abs_regs();
     store_rows_tile<BM>(smem, ra);
@@ -333,6 +393,36 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
   else k_loop(std::false_type{});
 
   // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+  if constexpr (FWD && VAR >= 1) {
+    if (interior) {
+      // all 32 loads of a 32x32 block in flight before the first use (the generic loop below waits per element:
+      // its rare exact_z call sits between consecutive loads)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
+          const int64_t gr0 = tc.row0 + wm * WM + mi * 32 + 4 * kh;
+          float rr[16], yy[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t at = (gr0 + (e & 3) + 8 * (e >> 2)) * Nn + gc;
+            rr[e] = R[at];
+            yy[e] = Y[at];
+          }
+          const float bb = bias ? bias[gc] : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t gr = gr0 + (e & 3) + 8 * (e >> 2);
+            const float a_abs = acc[0][mi][ni][e];
+            float z = 0.5f * ((yy[e] - bb) + a_abs);
+            if (!(z > kCancelTol * a_abs)) z = exact_z(X + gr * K, W + gc * K, K);
+            S1[gr * Nn + gc] = te_sd(rr[e], z);
+          }
+        }
+      return;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -598,22 +688,42 @@ inline Tile pick_tile(int64_t T, int64_t n_out, bool one_product = false) {
     const int64_t tiles = te_ceil_div(T, bm) * te_ceil_div(n_out, bn);
     return factor * ((double)tiles / kCUs) / (double)te_ceil_div(tiles, kCUs);
   };
-  // the one-product Z-pass has half the MFMAs per K-step: the wide tile's second co-resident block no longer covers
-  // its barriers (measured 80 vs 90 TF at out_f = 2304)
-  const double e0 = eff(128, 128, one_product ? 0.85 : 1.0), e1 = eff(128, 64, 0.98), e2 = eff(64, 64, 0.93);
+  // the one-product Z-pass has half the MFMAs per K-step and is bound by the latency of its global loads: the more
+  // co-resident waves the better (64x64: 5 blocks per CU), measured 64x64 >= 128x64 > 128x128 on every ViT-B shape
+  // (profiles/r01_zfwd_variants.log)
+  const double e0 = eff(128, 128, one_product ? 0.85 : 1.0), e1 = eff(128, 64, one_product ? 0.97 : 0.98),
+               e2 = eff(64, 64, one_product ? 1.0 : 0.93);
   if (e2 > e1 && e2 > e0) return TILE_64x64;
   return (e1 > e0) ? TILE_128x64 : TILE_128x128;
 }
 
-template <int ZM, bool SWAP, int BM, int BN>
-inline void launch_k1(const float* X, const float* W, const float* R, const float* Y, const float* bias, float* S1,
-                      float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream) {
+template <int ZM, bool SWAP, int BM, int BN, int VAR = 0>
+inline void launch_k1v(const float* X, const float* W, const float* R, const float* Y, const float* bias, float* S1,
+                       float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream) {
   const int nbn = (int)te_ceil_div(out_f, BN);
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k1_lds<BM, BN>();
-  allow_lds(linear_k1_kernel<ZM, SWAP, BM, BN>, lds);
-  linear_k1_kernel<ZM, SWAP, BM, BN><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
+  allow_lds(linear_k1_kernel<ZM, SWAP, BM, BN, VAR>, lds);
+  linear_k1_kernel<ZM, SWAP, BM, BN, VAR><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
       X, W, R, Y, bias, S1, S2, T, in_f, out_f, nbn, ntiles);
+}
+template <int ZM, bool SWAP, int BM, int BN>
+inline void launch_k1(const float* X, const float* W, const float* R, const float* Y, const float* bias, float* S1,
+                      float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream) {
+  if constexpr (ZM == ZM_FWD) {
+    // TE_ZFWD_VARIANT (tuning study, profiles/r01_zfwd_variants.log): 0 = per-element epilogue, distance-1 prefetch;
+    // 1 = batched epilogue loads (-3.5 %); 2 = 1 + prefetch distance 2 (-6.3 %, default)
+    static const int var = [] {
+      const char* e = getenv("TE_ZFWD_VARIANT");
+      return e ? atoi(e) : 2;
+    }();
+    switch (var) {
+      case 0: return launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
+      case 1: return launch_k1v<ZM, SWAP, BM, BN, 1>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
+      default: return launch_k1v<ZM, SWAP, BM, BN, 2>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
+    }
+  }
+  launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
 }
 template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
 inline void launch_k2(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,

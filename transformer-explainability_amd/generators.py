@@ -46,11 +46,17 @@ class LRP:
     the single-stream path sample by sample; the per-module caches (``get_attn_cam()`` ...) then hold the LAST
     micro-batch only."""
 
-    def __init__(self, model, streams=1):
+    def __init__(self, model, streams=1, overlap_backward=False):
         self.model = model
         self.model.eval()
         self.streams = max(1, int(streams))
         self._side = None
+        # (extension) the relprop chain reads only forward caches; the attention gradients are needed by the tail
+        # alone.  With overlap_backward the backward pass (main stream) and the relprop rules (side stream) run
+        # concurrently and join before the head-mean / rollout tail: the memory-bound backward kernels and the tails
+        # of the MFMA-bound Linear.relprop launches fill each other's idle CUs.  Same kernels, same results.
+        self.overlap_backward = bool(overlap_backward)
+        self._relprop_stream = None
 
     def generate_LRP(self, input, index=None, method="transformer_attribution", is_ablation=False, start_layer=0):
         B = input.shape[0]
@@ -86,8 +92,32 @@ class LRP:
         kwargs = {"alpha": 1}
         one_hot = _one_hot(output, index)
         loss = torch.sum(one_hot * output)
+        if self.overlap_backward and input.is_cuda:
+            return self._relprop_beside_backward(loss, one_hot, method, is_ablation, start_layer, kwargs)
         _attention_gradients(loss, [blk.attn for blk in self.model.blocks])
         return self.model.relprop(one_hot, method=method, is_ablation=is_ablation, start_layer=start_layer, **kwargs)
+
+    def _relprop_beside_backward(self, loss, one_hot, method, is_ablation, start_layer, kwargs):
+        dev = one_hot.device
+        main = torch.cuda.current_stream(dev)
+        if self._relprop_stream is None:
+            self._relprop_stream = torch.cuda.Stream(device=dev)
+        side = self._relprop_stream
+        side.wait_stream(main)                      # forward caches + one-hot are complete
+        # backward on the main stream (autograd runs each node on its forward op's stream)
+        _attention_gradients(loss, [blk.attn for blk in self.model.blocks])
+        grads_ready = main.record_event()
+        self.model._before_tail = lambda: torch.cuda.current_stream(dev).wait_event(grads_ready)
+        try:
+            with torch.cuda.stream(side):
+                out = self.model.relprop(one_hot, method=method, is_ablation=is_ablation, start_layer=start_layer,
+                                         **kwargs)
+        finally:
+            self.model._before_tail = None
+        main.wait_stream(side)
+        if out is not None and not torch.cuda.is_current_stream_capturing():
+            out.record_stream(main)
+        return out
 
 
 class Baselines:

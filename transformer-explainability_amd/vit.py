@@ -271,6 +271,10 @@ def make_vit_module(L):
             for blk in reversed(rest):
                 cam = blk.relprop(cam, **kwargs)
 
+            hook = getattr(self, "_before_tail", None)    # LRP(overlap_backward=True): join with the backward pass here
+            if hook is not None:
+                hook()
+
             if method == "full":
                 # ViT_LRP.py:337-343: position-embedding Add, drop the class token, z^B rule of the patch
                 # embedding, sum over the colour channels -> [B, H, W]
