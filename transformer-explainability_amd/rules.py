@@ -124,6 +124,14 @@ class einsum(RelProp):
         self.equation = equation
 
     def forward(self, *operands):
+        ops_ = operands[0] if (len(operands) == 1 and isinstance(operands[0], (list, tuple))) else operands
+        eq = self.equation.replace(" ", "")
+        # the two attention products as plain batched matmuls: torch.einsum materialises k^T first (a [B,H,D,N] copy
+        # per block); matmul hands the transposed strides to the BLAS
+        if eq == 'bhid,bhjd->bhij' and len(ops_) == 2:
+            return torch.matmul(ops_[0], ops_[1].transpose(-1, -2))
+        if eq == 'bhij,bhjd->bhid' and len(ops_) == 2:
+            return torch.matmul(ops_[0], ops_[1])
         return torch.einsum(self.equation, *operands)
 
     def relprop(self, R, alpha):
