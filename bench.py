@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--graph", choices=["on", "off"], default="on",
                     help="replay each step from a HIP graph (one eager step inside the timed region carries the "
                          "per-kernel HIP events of the roofline)")
+    ap.add_argument("--tuned-gemms", choices=["on", "off", "tune"], default="on",
+                    help="stock fp32 GEMMs of forward/backward selected by PyTorch TunableOp from the committed results "
+                         "file (on), PyTorch's default heuristic (off), or tune now and write gpurun_out/ (tune)")
     ap.add_argument("--overlap-backward", choices=["on", "off"], default="off",
                     help="run the relprop rules on a side stream beside the attention-gradient backward pass (they are "
                          "independent until the head-mean / rollout tail); the roofline probe step stays serial")
@@ -181,6 +184,12 @@ def main():
     te._lib.require_device()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    tuned = False
+    if args.tuned_gemms == "on":
+        tuned = te.enable_tuned_gemms()
+    elif args.tuned_gemms == "tune":
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        tuned = te.enable_tuned_gemms(os.path.join(ROOT, "gpurun_out", f"tunableop_gfx950_rank{rank}.csv"), tune=True)
 
     torch.manual_seed(0)
     model = vit.vit_base_patch16_224().eval()
@@ -286,6 +295,9 @@ def main():
                        "start_layer": args.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "streams": args.streams, "steps_in_flight": args.inflight,
                        "relprop_beside_backward": args.overlap_backward == "on",
+                       "stock_gemm_selection": ("PyTorch TunableOp, committed results file" if tuned and
+                                                args.tuned_gemms == "on" else
+                                                "PyTorch TunableOp, tuned in this run" if tuned else "PyTorch default"),
                        "hip_graph": graphed is not None, "parallelism": f"dp{world} (independent samples, one "
                                                                       f"all_gather of the maps)"},
         }

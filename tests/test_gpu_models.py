@@ -252,6 +252,28 @@ def test_bert_tiny_other_methods(golden_bert_tiny, golden_methods):
     check_nan_aware("bert_tiny.attn_gradcam", gen.generate_attn_gradcam(ids, mask), gm["bert.attn_gradcam"], 1e-3)
 
 
+def test_tuned_stock_gemms(vit_b16):
+    """enable_tuned_gemms() only changes which stock fp32 GEMM kernels forward / backward run: the maps stay within the
+    cross-producer band of the default kernels, and HIP relprop == oracle on the tensors that forward produced."""
+    import torch.cuda.tunable as tunable
+    import transformer_explainability_amd as te
+    from transformer_explainability_amd.generators import LRP
+    model = vit_b16.to(dev())
+    x = seeded_randn((2, 3, 224, 224), 1).to(dev())
+    lrp = LRP(model)
+    base = lrp.generate_LRP(x, start_layer=1).clone()
+    assert te.enable_tuned_gemms()
+    try:
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        tuned = lrp.generate_LRP(x, start_layer=1).clone()
+        cache = vit_cache_from_model(model)
+        ref = O.vit_relprop(_one_hot_of(model.head.Y.detach().cpu()), cache, num_heads=12, start_layer=1)["map"]
+    finally:
+        tunable.enable(False)
+    _assert_map("vit_b16.tuned_gemms.same_cache_oracle", tuned, ref)
+    _assert_map("vit_b16.tuned_vs_default_gemms", tuned, base, **LOOSE)
+
+
 # ------------------------------------------------------------------------------------------ ViT-B/16 full size
 @pytest.fixture(scope="module")
 def vit_b16():

@@ -11,6 +11,8 @@ directory name carries a hyphen).  Layout:
   generators.py                     LRP.generate_LRP / Generator.generate_LRP
   dropin/                           the reference's import paths (modules.layers_ours, baselines.ViT.ViT_LRP, ...)
   parallel.py                       one-process-per-GPU sharding + RCCL gather of the finished maps
+  sweep.py, perturbation.py, segmentation.py   the evaluation protocols around the maps
+  tuning/                           PyTorch TunableOp selection of the stock fp32 GEMMs of forward + backward
 """
 from . import _lib, ops, rules, rules_lrp  # noqa: F401
 from ._lib import TeError, LIB_PATH  # noqa: F401
@@ -34,3 +36,29 @@ def install_dropin() -> str:
         if p not in sys.path:
             sys.path.insert(0, p)
     return d
+
+
+def enable_tuned_gemms(path=None, tune=False) -> bool:
+    """Producers: the ViT / BERT forward and attention-gradient backward stay on stock PyTorch-ROCm,
+    whose default heuristic picks fp32 GEMM kernels that run at 97-125 TF on the ViT-B/16 batch-64 shapes; PyTorch's
+    own TunableOp, given one tuning pass over rocBLAS / hipBLASLt's solutions, finds ones at 117-148 TF (+7 % on the
+    whole generate_LRP step).  This loads the committed selection for gfx950 (tuning/tunableop_gfx950.csv, keyed by
+    GEMM shape and validated against the PyTorch / rocBLAS / hipBLASLt versions; unknown shapes keep the default
+    kernel).  ``tune=True`` additionally tunes shapes the file does not hold (seconds per shape, then written back to
+    ``path``).  Returns False when TunableOp is unavailable."""
+    import os
+    import torch
+    try:
+        import torch.cuda.tunable as tunable
+    except ImportError:
+        return False
+    if not torch.cuda.is_available():
+        return False
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune))
+    tunable.set_filename(path, insert_device_ordinal=False)
+    if os.path.exists(path):
+        tunable.read_file(path)
+    return True
