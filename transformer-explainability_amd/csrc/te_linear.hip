@@ -605,152 +605,6 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2s: the C-pass (MODE 0) with wave-private operands and a 4-way split of K inside the workgroup.
-//
-// Modelled on what the best stock fp32 GEMM for these shapes does (rocBLAS's MT64x32x64_MI16x16x4 winner under
-// TunableOp: 136-148 TF at T = 12,608): a SMALL macro tile (64 x 32 outputs per 4-wave workgroup: 4728 workgroups for
-// a 12,608 x 768 output = 18.5 per CU, 97 % full in the last round where 128 x 64 tiles are 93 %), whose four waves
-// each take every fourth 32-deep K chunk of the WHOLE tile (so the unit of scheduling is a quarter of a tile's work on
-// one SIMD), operands loaded from global memory straight into the MFMA fragment layout (no LDS staging, no barrier in
-// the main loop: each wave runs its own two-stage register pipeline), and one reduction of the four partial
-// accumulators through LDS at the end, summed in the fixed order ((w0 + w1) + w2) + w3 -- the summation grouping of an
-// output element depends on K alone, never on the tile's position or the launch size, so the bitwise
-// "batch = per-sample" property holds.
-//   A fragment: lane (lr, kh) reads S[row0 + mi*32 + lr][k0 + kg*8 + kh*4 .. +3] as one dwordx4 (4 consecutive MFMAs)
-//   B fragment: lane (lr, kh) reads W[k0 + kg*8 + kh*4 + j][col0 + lr] as dwords (two full 128-B rows per instruction)
-// ------------------------------------------------------------------------------------------------
-constexpr int kLsuBM = 64, kLsuBN = 32;
-constexpr size_t kLsuLds = 4 * 4 * 4 * 64 * sizeof(f32x4);   // [wave][P0,P1,N0,N1][e-quad][lane] = 64 KiB
-
-// DIAG (tuning builds, wrong results): 1 = no +/- split, 2 = A loaded once, 3 = B loaded once, 4 = no loads at all
-// after the prologue, 5 = no split-K reduction
-template <int DIAG = 0>
-__global__ __launch_bounds__(kThreads, 2) void linear_k2_lsu_kernel(
-    const float* __restrict__ S, const float* __restrict__ W, const float* __restrict__ X,
-    float* __restrict__ out, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: chunk offsets stay in SGPRs
-  const int lane = threadIdx.x & 63;
-  const int lr = lane & 31, kh = lane >> 5;
-  const TileCoord tc = tile_coord<kLsuBM, kLsuBN>(blockIdx.x, ntiles, nbn);
-  const int nchunks = (int)(K / BK);
-  const int n_w = (nchunks - wave + 3) >> 2;            // chunks of this wave: wave, wave + 4, ...
-
-  // per-lane 32-bit element offsets from wave-uniform bases (S and W are < 2^32 bytes: checked by the launcher);
-  // rows past T read row T-1 (valid memory), their results are dropped by the guarded stores
-  const int64_t r0 = (tc.row0 + lr < T) ? tc.row0 + lr : T - 1;
-  const int64_t r1 = (tc.row0 + 32 + lr < T) ? tc.row0 + 32 + lr : T - 1;
-  const uint32_t oa0 = (uint32_t)(r0 * K + kh * 4);
-  const uint32_t oa1 = (uint32_t)(r1 * K + kh * 4);
-  const uint32_t ob = (uint32_t)((int64_t)(kh * 4) * Nn + lr);
-  const float* __restrict__ Wt = W + tc.col0;           // uniform
-
-  f32x16 accP[2], accN[2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      accP[mi][e] = 0.0f;
-      accN[mi][e] = 0.0f;
-    }
-
-  struct Stage {
-    f32x4 a[2][4];
-    float b[16];
-  };
-  auto load = [&](Stage& st, int i) __attribute__((always_inline)) {
-    const int64_t k0 = (int64_t)(wave + 4 * i) * BK;    // uniform
-    const float* __restrict__ Sk = S + k0;
-    const float* __restrict__ Wk = Wt + k0 * Nn;
-    if (!((DIAG == 2 || DIAG == 4) && i >= 2)) {
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
-        st.a[0][kg] = *reinterpret_cast<const f32x4*>(Sk + kg * 8 + oa0);
-        st.a[1][kg] = *reinterpret_cast<const f32x4*>(Sk + kg * 8 + oa1);
-      }
-    }
-    if (!((DIAG == 3 || DIAG == 4) && i >= 2)) {
-#pragma unroll
-      for (int kg = 0; kg < 4; ++kg)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) st.b[kg * 4 + j] = (Wk + (int64_t)(kg * 8 + j) * Nn)[ob];
-    }
-  };
-  auto compute = [&](const Stage& st) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float b = st.b[kg * 4 + j];
-        const float bp = (DIAG == 1) ? b : te_pos(b), bn = (DIAG == 1) ? b : te_neg(b);
-        accP[0] = TE_MFMA(st.a[0][kg][j], bp, accP[0]);
-        accP[1] = TE_MFMA(st.a[1][kg][j], bp, accP[1]);
-        accN[0] = TE_MFMA(st.a[0][kg][j], bn, accN[0]);
-        accN[1] = TE_MFMA(st.a[1][kg][j], bn, accN[1]);
-      }
-  };
-
-  // two register stages; the steady-state loop is branch-free (both refills exist), the last <= 3 chunks are peeled
-  Stage s0, s1;
-  if (n_w > 0) load(s0, 0);
-  if (n_w > 1) load(s1, 1);
-  int i = 0;
-  for (; i + 3 < n_w; i += 2) {
-    compute(s0);
-    load(s0, i + 2);
-    compute(s1);
-    load(s1, i + 3);
-  }
-  if (i < n_w) {
-    compute(s0);
-    if (i + 2 < n_w) load(s0, i + 2);
-  }
-  if (i + 1 < n_w) compute(s1);
-  if (i + 2 < n_w) compute(s0);
-
-  // partial accumulators -> LDS: [wave][vec][e-quad][lane] as float4, conflict-free b128
-  f32x4* red = reinterpret_cast<f32x4*>(smem);
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const f32x16& a = (v == 0) ? accP[0] : (v == 1) ? accP[1] : (v == 2) ? accN[0] : accN[1];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 t = {a[q * 4 + 0], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
-      red[((wave * 4 + v) * 4 + q) * 64 + lane] = t;
-    }
-  }
-  if (DIAG != 5) __syncthreads();
-  // wave w finishes row block mi = w >> 1, accumulator elements [8 * (w & 1), +8)
-  const int mi = wave >> 1, q0 = (wave & 1) * 2;
-  const int64_t gc = tc.col0 + lr;
-#pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    const int q = q0 + qq;
-    f32x4 p = red[((0 * 4 + mi) * 4 + q) * 64 + lane];
-    f32x4 n = red[((0 * 4 + 2 + mi) * 4 + q) * 64 + lane];
-#pragma unroll
-    for (int w = 1; w < (DIAG == 5 ? 1 : 4); ++w) {
-      const f32x4 pw = red[((w * 4 + mi) * 4 + q) * 64 + lane];
-      const f32x4 nw = red[((w * 4 + 2 + mi) * 4 + q) * 64 + lane];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        p[i] = p[i] + pw[i];
-        n[i] = n[i] + nw[i];
-      }
-    }
-    // C/D layout of the 32x32 MFMA: element e = q*4 + i sits at row (e & 3) + 8 * (e >> 2) + 4 * kh = i + 8 * q + 4 * kh
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t gr = tc.row0 + mi * 32 + i + 8 * q + 4 * kh;
-      if (gr < T) {
-        const float x = X[gr * Nn + gc];
-        out[gr * Nn + gc] = scale * (fmaxf(x, 0.0f) * p[i] + fminf(x, 0.0f) * n[i]);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // simple kernels (any shape): one thread per output element, k-ordered fmaf chains
 // ------------------------------------------------------------------------------------------------
 template <bool LRP, bool SWAP>
@@ -882,37 +736,6 @@ inline void launch_k2(const float* S, const float* W, const float* X, float* out
       S, W, X, out, T, out_f, in_f, nbn, ntiles, scale, zb);
 }
 
-// the wave-private / split-K C-pass (K2s): out_f (= K) and in_f multiples of 32; TE_CPASS_KERNEL=tiled keeps K2
-inline bool launch_k2_lsu(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
-                          int64_t out_f, float scale, hipStream_t stream) {
-  static const bool enabled = [] {
-    const char* e = getenv("TE_CPASS_KERNEL");
-    return !(e && !strcmp(e, "tiled"));
-  }();
-  if (!enabled || (out_f % BK) || (in_f % kLsuBN)) return false;
-  if ((uint64_t)T * (uint64_t)out_f >= (1ull << 30) || (uint64_t)out_f * (uint64_t)in_f >= (1ull << 30)) return false;
-  const int nbn = (int)(in_f / kLsuBN);
-  const int64_t nt = te_ceil_div(T, kLsuBM) * nbn;
-  if (nt > 0x7fffffff) return false;
-  static const int diag = [] {
-    const char* e = getenv("TE_LSU_DIAG");
-    return e ? atoi(e) : 0;
-  }();
-#define TE_LSU(D)                                                                                                  \
-  linear_k2_lsu_kernel<D><<<dim3((unsigned)nt), dim3(kThreads), kLsuLds, stream>>>(S, W, X, out, T, out_f, in_f, nbn, \
-                                                                                  (int)nt, scale)
-  switch (diag) {
-    case 1: TE_LSU(1); break;
-    case 2: TE_LSU(2); break;
-    case 3: TE_LSU(3); break;
-    case 4: TE_LSU(4); break;
-    case 5: TE_LSU(5); break;
-    default: TE_LSU(0); break;
-  }
-#undef TE_LSU
-  return true;
-}
-
 #define TE_DISPATCH_TILE(tile, CALL)                  \
   do {                                                \
     switch (tile) {                                   \
@@ -952,13 +775,9 @@ int run_half(const float* R, const float* X, const float* W, float* out, int64_t
 #define TE_K1(BM_, BN_) launch_k1<ZM_OURS, SWAP, BM_, BN_>(X, W, R, nullptr, nullptr, S1, S1, T, in_f, out_f, stream)
     TE_DISPATCH_TILE(t1, TE_K1);
 #undef TE_K1
-    bool done = false;
-    if constexpr (!SWAP && !ACCUM) done = launch_k2_lsu(S1, W, X, out, T, in_f, out_f, scale, stream);
-    if (!done) {
 #define TE_K2(BM_, BN_) launch_k2<0, SWAP, ACCUM, BM_, BN_>(S1, W, X, out, T, in_f, out_f, scale, stream)
-      TE_DISPATCH_TILE(t2, TE_K2);
+    TE_DISPATCH_TILE(t2, TE_K2);
 #undef TE_K2
-    }
   }
   return TE_OK;
 }
@@ -998,10 +817,6 @@ extern "C" int te_linear_cpass_f32(const float* S, const float* X, const float* 
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(S) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(out))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-  if (launch_k2_lsu(S, W, X, out, T, in_f, out_f, 1.0f, stream)) {
-    TE_RETURN_IF_LAUNCH_FAILED();
-    return TE_OK;
-  }
 #define TE_K2(BM_, BN_) launch_k2<0, false, false, BM_, BN_>(S, W, X, out, T, in_f, out_f, 1.0f, stream)
   TE_DISPATCH_TILE(pick_tile(T, in_f), TE_K2);
 #undef TE_K2
