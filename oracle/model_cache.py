@@ -4,7 +4,6 @@ gradients) into the dict layout the CPU oracle consumes (oracle/relprop_oracle.p
 TEST INFRASTRUCTURE ONLY (see oracle/relprop_oracle.py header): used by tests/, __graft_entry__.smoke()
 and bench.py's cpu_baseline leg to run the oracle on exactly the activations the HIP path consumed.
 """
-import torch
 
 
 def _cpu(t):

@@ -5,8 +5,6 @@ stride/view plumbing, generators, sharding) on a machine without a GPU.  The pro
 """
 import contextlib
 
-import torch
-
 from oracle import relprop_oracle as O
 
 

@@ -3,8 +3,6 @@ bare module names used by the scripts that run from baselines/ViT, package paths
 import subprocess
 import sys
 
-import pytest
-
 IMPORTS = r'''
 import sys
 sys.path.insert(0, %r)

@@ -4,7 +4,6 @@ reference, so they also pin our forward pass and state_dict layout."""
 import pytest
 import torch
 
-from conftest import unflatten_cache
 from oracle_backend import oracle_ops
 
 
