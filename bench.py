@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--tuned-gemms", choices=["on", "off", "tune"], default="on",
                     help="stock fp32 GEMMs of forward/backward selected by PyTorch TunableOp from the committed results "
                          "file (on), PyTorch's default heuristic (off), or tune now and write gpurun_out/ (tune)")
+    ap.add_argument("--prune", choices=["on", "off"], default="off",
+                    help="skip the relprop rules and attention gradients of the blocks below --start-layer (their "
+                         "attn_cam never reaches the map); off = every block, as the reference does")
     ap.add_argument("--overlap-backward", choices=["on", "off"], default="off",
                     help="run the relprop rules on a side stream beside the attention-gradient backward pass (they are "
                          "independent until the head-mean / rollout tail); the roofline probe step stays serial")
@@ -201,7 +204,8 @@ def main():
     model.to(dev)
     B = args.batch
     x = torch.stack([synthetic_image(rank * B + i) for i in range(B)]).to(dev)
-    lrp = LRP(model, streams=args.streams, overlap_backward=(args.overlap_backward == "on"))
+    lrp = LRP(model, streams=args.streams, overlap_backward=(args.overlap_backward == "on"),
+              prune=(args.prune == "on"))
     log(f"rank {rank}/{world}: model + {B} images resident on {dev}")
 
     timer = KernelTimer()
@@ -295,6 +299,7 @@ def main():
                        "start_layer": args.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "streams": args.streams, "steps_in_flight": args.inflight,
                        "relprop_beside_backward": args.overlap_backward == "on",
+                       "blocks_below_start_layer_pruned": args.prune == "on",
                        "stock_gemm_selection": ("PyTorch TunableOp, committed results file" if tuned and
                                                 args.tuned_gemms == "on" else
                                                 "PyTorch TunableOp, tuned in this run" if tuned else "PyTorch default"),

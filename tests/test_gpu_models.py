@@ -231,6 +231,22 @@ def test_bert_tiny_golden(golden_bert_tiny):
     assert abs(float(cam.double().sum()) - 1.0) < 1e-4
 
 
+def test_bert_base_pruned_default_start_layer(golden_bert_base):
+    """Generator(prune=True) at the reference's default start_layer = 11: only the last layer's rules run; same vector."""
+    from transformer_explainability_amd import bert
+    from transformer_explainability_amd.generators import Generator
+    g = golden_bert_base
+    model = bert.BertForSequenceClassification(bert.BertConfigLite(num_labels=2)).eval()
+    synthetic_init(model, 0)
+    model.to(dev())
+    ids, mask = g["input_ids"].long().to(dev()), g["attention_mask"].to(dev())
+    for sl in (11, 0):
+        full = Generator(model).generate_LRP(ids, mask, start_layer=sl).clone()
+        assert torch.equal(Generator(model, prune=True).generate_LRP(ids, mask, start_layer=sl), full)
+    _assert_map("bert_base.pruned_sl11.golden", Generator(model, prune=True).generate_LRP(ids, mask), g["map_sl11"],
+                **LOOSE)
+
+
 def test_bert_tiny_other_methods(golden_bert_tiny, golden_methods):
     """ExplanationGenerator.py:62-155, batched, vs the reference's per-sample outputs."""
     from transformer_explainability_amd import bert
@@ -408,6 +424,10 @@ def test_vit_b16_batch_equals_singles(vit_b16):
     assert torch.equal(glrp(x), batch)
     assert torch.equal(glrp(x2), replayed)
     del glrp
+    # pruned below start_layer == the full pass, bitwise (the skipped rules never reach the map)
+    assert torch.equal(LRP(model, prune=True).generate_LRP(x, start_layer=1), batch)
+    assert torch.equal(LRP(model, prune=True, overlap_backward=True).generate_LRP(x2, start_layer=1), replayed)
+    model.prune_below_start_layer = False
     singles = torch.cat([lrp.generate_LRP(x[i:i + 1], start_layer=1) for i in range(B)], 0)
     _assert_map("vit_b16.batch_vs_separate_forwards", batch, singles, **LOOSE)
     # LRP conservation: the token relevance of every sample sums to 1

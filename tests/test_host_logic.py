@@ -97,6 +97,25 @@ def test_baselines_against_reference(golden_methods):
             assert _rel(b.generate_rollout(x, start_layer=sl).detach(), gm[f"baselines.rollout_sl{sl}"]) < 1e-5
 
 
+@pytest.mark.parametrize("start_layer", [0, 1, 2])
+def test_vit_pruned_relprop_is_bitwise_the_full_one(tiny_vit, golden_vit_tiny, start_layer):
+    """LRP(prune=True): stop after block start_layer's attn_cam, attention gradients of blocks >= start_layer only."""
+    from transformer_explainability_amd.generators import LRP
+    g = golden_vit_tiny
+    with oracle_ops():
+        full = LRP(tiny_vit).generate_LRP(g["x"], start_layer=start_layer).clone()
+        for blk in tiny_vit.blocks:
+            blk.attn.attn_cam = None
+        pruned = LRP(tiny_vit, prune=True).generate_LRP(g["x"], start_layer=start_layer)
+        assert torch.equal(full, pruned)
+        assert all((blk.attn.get_attn_cam() is None) == (i < start_layer) for i, blk in enumerate(tiny_vit.blocks))
+        assert not any(getattr(blk.attn, "_stop_after_attn_cam", False) for blk in tiny_vit.blocks)
+        # other methods are served in full whatever the flag says
+        out = LRP(tiny_vit, prune=True).generate_LRP(g["x"], method="rollout", start_layer=1)
+        assert all(blk.attn.get_attn_cam() is not None for blk in tiny_vit.blocks) and out.shape == (2, 16)
+    tiny_vit.prune_below_start_layer = False
+
+
 def test_vit_lrp_variant(golden_vit_tiny):
     from transformer_explainability_amd import rules_lrp, vit
     from transformer_explainability_amd.generators import LRP
@@ -147,6 +166,24 @@ def test_bert_other_generator_methods(tiny_bert, golden_bert_tiny, golden_method
         assert _rel(gen.generate_rollout(ids, mask, start_layer=0).detach(), gm["bert.rollout_sl0"]) < 1e-5
         assert _rel(gen.generate_rollout(ids, mask, start_layer=1).detach(), gm["bert.rollout_sl1"]) < 1e-5
         assert _rel(gen.generate_attn_gradcam(ids, mask).detach(), gm["bert.attn_gradcam"]) < 1e-4
+
+
+@pytest.mark.parametrize("start_layer", [0, 1, 2])
+def test_bert_pruned_relprop_is_bitwise_the_full_one(tiny_bert, golden_bert_tiny, start_layer):
+    from transformer_explainability_amd.generators import Generator
+    g = golden_bert_tiny
+    ids, mask = g["input_ids"].long(), g["attention_mask"]
+    with oracle_ops():
+        full = Generator(tiny_bert).generate_LRP(ids, mask, start_layer=start_layer).clone()
+        last = Generator(tiny_bert).generate_LRP_last_layer(ids, mask).clone()
+        for lay in tiny_bert.bert.encoder.layer:
+            lay.attention.self.attn_cam = None
+        gen = Generator(tiny_bert, prune=True)
+        assert torch.equal(gen.generate_LRP(ids, mask, start_layer=start_layer), full)
+        cams = [lay.attention.self.get_attn_cam() for lay in tiny_bert.bert.encoder.layer]
+        assert all((c is None) == (i < start_layer) for i, c in enumerate(cams))
+        assert torch.equal(gen.generate_LRP_last_layer(ids, mask), last)
+        assert torch.equal(gen.generate_full_lrp(ids, mask), Generator(tiny_bert).generate_full_lrp(ids, mask))
 
 
 def test_bert_full_relprop_conservation(tiny_bert, golden_bert_tiny):

@@ -134,6 +134,8 @@ def make_bert_module(L):
             cam1, _ = ops.matmul_relprop_av(as_heads(cam), probs, v, out_scale=0.5, cam_v_out=as_heads(rv), variant=var,
                                             z=getattr(self.matmul2, "Y", None))
             self.save_attn_cam(cam1)
+            if getattr(self, "_stop_after_attn_cam", False):   # Generator(prune=True): nothing below is read
+                raise L.StopRelprop()
             if self.attention_mask is not None:
                 cam1, _ = self.add.relprop(cam1, **kwargs)                          # BERT.py:386-388
             ops.matmul_relprop_qk(cam1, q, kt.transpose(-1, -2), out_scale=0.5, cam_q_out=as_heads(rq),

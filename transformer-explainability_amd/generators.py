@@ -46,7 +46,7 @@ class LRP:
     the single-stream path sample by sample; the per-module caches (``get_attn_cam()`` ...) then hold the LAST
     micro-batch only."""
 
-    def __init__(self, model, streams=1, overlap_backward=False):
+    def __init__(self, model, streams=1, overlap_backward=False, prune=False):
         self.model = model
         self.model.eval()
         self.streams = max(1, int(streams))
@@ -57,6 +57,9 @@ class LRP:
         # of the MFMA-bound Linear.relprop launches fill each other's idle CUs.  Same kernels, same results.
         self.overlap_backward = bool(overlap_backward)
         self._relprop_stream = None
+        # (extension, off by default) only the blocks >= start_layer contribute to a transformer_attribution map: skip
+        # the relprop rules and the attention-gradient backward below them (model.prune_below_start_layer)
+        self.prune = bool(prune)
 
     def generate_LRP(self, input, index=None, method="transformer_attribution", is_ablation=False, start_layer=0):
         B = input.shape[0]
@@ -92,9 +95,12 @@ class LRP:
         kwargs = {"alpha": 1}
         one_hot = _one_hot(output, index)
         loss = torch.sum(one_hot * output)
+        prune = self.prune and method in ("transformer_attribution", "grad")
+        self.model.prune_below_start_layer = prune
+        self._grad_blocks = list(self.model.blocks)[start_layer if prune else 0:]
         if self.overlap_backward and input.is_cuda:
             return self._relprop_beside_backward(loss, one_hot, method, is_ablation, start_layer, kwargs)
-        _attention_gradients(loss, [blk.attn for blk in self.model.blocks])
+        _attention_gradients(loss, [blk.attn for blk in self._grad_blocks])
         return self.model.relprop(one_hot, method=method, is_ablation=is_ablation, start_layer=start_layer, **kwargs)
 
     def _relprop_beside_backward(self, loss, one_hot, method, is_ablation, start_layer, kwargs):
@@ -105,7 +111,7 @@ class LRP:
         side = self._relprop_stream
         side.wait_stream(main)                      # forward caches + one-hot are complete
         # backward on the main stream (autograd runs each node on its forward op's stream)
-        _attention_gradients(loss, [blk.attn for blk in self.model.blocks])
+        _attention_gradients(loss, [blk.attn for blk in self._grad_blocks])
         grads_ready = main.record_event()
         self.model._before_tail = lambda: torch.cuda.current_stream(dev).wait_event(grads_ready)
         try:
@@ -229,42 +235,61 @@ class GraphedLRP:
 class Generator:
     """BERT_explainability/modules/BERT/ExplanationGenerator.py:20-59 (generate_LRP)."""
 
-    def __init__(self, model):
+    def __init__(self, model, prune=False):
         self.model = model
         self.model.eval()
+        # (extension, off by default) generate_LRP reads attn_cam / attention gradients of the layers >= start_layer
+        # only (ExplanationGenerator.py:47-57) -- with the reference's default start_layer = 11 that is the LAST layer
+        # alone, yet relevance and gradients are propagated through all twelve.  prune=True stops the relprop right
+        # after layer start_layer's attn_cam is stored and asks autograd for the gradients of those layers only: the
+        # same vector bit for bit; get_attn_cam() of the layers below is then not refreshed.
+        self.prune = bool(prune)
 
     def forward(self, input_ids, attention_mask):
         return self.model(input_ids, attention_mask)
 
-    def _explain(self, input_ids, attention_mask, index):
+    def _explain(self, input_ids, attention_mask, index, lowest_layer=0):
+        """forward, attention-gradient backward, relprop.  With prune=True only the layers >= lowest_layer are served."""
+        from .rules import StopRelprop
         output = self.model(input_ids=input_ids, attention_mask=attention_mask)[0]
         one_hot = _one_hot(output, index)
         loss = torch.sum(one_hot * output)
         layers = self.model.bert.encoder.layer
-        _attention_gradients(loss, [lay.attention.self for lay in layers])
-        self.model.relprop(one_hot, alpha=1)
+        first = lowest_layer if self.prune else 0
+        _attention_gradients(loss, [lay.attention.self for lay in list(layers)[first:]])
+        stop_at = layers[first].attention.self if self.prune else None
+        if stop_at is not None:
+            stop_at._stop_after_attn_cam = True
+        try:
+            self.model.relprop(one_hot, alpha=1)
+        except StopRelprop:
+            pass
+        finally:
+            if stop_at is not None:
+                stop_at._stop_after_attn_cam = False
         return layers
 
     def generate_LRP(self, input_ids, attention_mask, index=None, start_layer=11):
-        self._explain(input_ids, attention_mask, index)
+        self._explain(input_ids, attention_mask, index, lowest_layer=start_layer)
         return self.attribution_tail(start_layer)
 
     def attribution_tail(self, start_layer=11):
         """ExplanationGenerator.py:47-59 on the attn_cam / attention gradients cached by relprop + backward."""
         layers = self.model.bert.encoder.layer
-        first = layers[0].attention.self.get_attn_cam()
+        first = layers[-1].attention.self.get_attn_cam()
         B, _, N, _ = first.shape
         stack = torch.empty((len(layers), B, N, N), dtype=first.dtype, device=first.device)
         for i, lay in enumerate(layers):
             sa = lay.attention.self
-            ops.gradcam_headmean(sa.get_attn_gradients(), sa.get_attn_cam(), out=stack[i])
+            if i >= start_layer or not self.prune:            # (the rollout reads layers >= start_layer only)
+                ops.gradcam_headmean(sa.get_attn_gradients(), sa.get_attn_cam(), out=stack[i])
         # ExplanationGenerator.py:7-18 (row-normalised rollout) + :58 (CLS fix-up) -> row 0
         joint = ops.rollout(stack, start_layer=start_layer, normalise=True, cls_fixup=True)
         return joint[:, 0]
 
     def generate_LRP_last_layer(self, input_ids, attention_mask, index=None):
         """ExplanationGenerator.py:62-84: head-mean of the last layer's attn_cam, CLS row, CLS slot zeroed."""
-        layers = self._explain(input_ids, attention_mask, index)
+        layers = self._explain(input_ids, attention_mask, index, lowest_layer=len(self.model.bert.encoder.layer) - 1)
         cam = layers[-1].attention.self.get_attn_cam().clamp(min=0).mean(dim=1)[:, 0].clone()
         cam[:, 0] = 0
         return cam
@@ -303,7 +328,7 @@ class Generator:
     def generate_attn_gradcam(self, input_ids, attention_mask, index=None):
         """ExplanationGenerator.py:129-155: last layer's attention x its per-head mean gradient, head-mean, clamped,
         min-max normalised over the whole [N, N] map, CLS row with the CLS slot zeroed."""
-        layers = self._explain(input_ids, attention_mask, index)
+        layers = self._explain(input_ids, attention_mask, index, lowest_layer=len(self.model.bert.encoder.layer) - 1)
         sa = layers[-1].attention.self
         cam = sa.get_attn().detach()
         grad = sa.get_attn_gradients().mean(dim=[2, 3], keepdim=True)

@@ -43,6 +43,11 @@ def forward_hook(self, input, output):
     self.Y = output
 
 
+class StopRelprop(Exception):
+    """Raised by an attention module whose ``_stop_after_attn_cam`` flag is set, right after it stored its attn_cam:
+    the model-level relprop loop catches it (extension: ``prune_below_start_layer``, see vit.VisionTransformer)."""
+
+
 def _cached_y(module):
     """The forward output forward_hook stored (the product whose rule is being evaluated), or None."""
     y = getattr(module, "Y", None)

@@ -4,6 +4,7 @@ RelPropSimple without the per-sample rescale: layers_lrp.py:98-100)."""
 from . import rules as _r
 from .rules import *  # noqa: F401,F403
 from .rules import __all__  # noqa: F401
+from .rules import StopRelprop  # noqa: F401
 
 
 class RelProp(_r.RelProp):

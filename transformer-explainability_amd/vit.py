@@ -146,6 +146,8 @@ def make_vit_module(L):
                                                 z=getattr(self.matmul2, "Y", None))
             self.save_v_cam(cam_v)
             self.save_attn_cam(cam1)
+            if getattr(self, "_stop_after_attn_cam", False):
+                raise L.StopRelprop()
             ops.matmul_relprop_qk(cam1, q, k, out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1], variant=var,
                                   z=getattr(self.matmul1, "Y", None))
             return self.qkv.relprop(cam_qkv, **kwargs)
@@ -250,6 +252,11 @@ def make_vit_module(L):
             self.add = L.Add()
             self.inp_grad = None
             self.exploit_cls_sparsity = True     # exact; set False to evaluate the last block densely
+            # (extension, off by default) "transformer_attribution" / "grad" read attn_cam of blocks >= start_layer only
+            # (ViT_LRP.py:357-369), yet the reference propagates relevance through every block.  With this flag the
+            # loop stops right after block start_layer's AV rule stored its attn_cam: same map bit for bit, 1/L of the
+            # relprop work less per skipped block -- but get_attn_cam() of blocks < start_layer is no longer refreshed.
+            self.prune_below_start_layer = False
             self.register_buffer("_cls_index", torch.zeros((), dtype=torch.long), persistent=False)
 
         def save_inp_grad(self, grad): self.inp_grad = grad
@@ -287,18 +294,28 @@ def make_vit_module(L):
             """ViT_LRP.py:324-398.  cam: one-hot [B, num_classes]; returns per-sample maps."""
             if method is None:
                 method = self.default_method
-            cam = self.head.relprop(cam, **kwargs)
-            if self.exploit_cls_sparsity and isinstance(self.head, nn.Linear):
-                # pool.relprop puts relevance on the class token only: keep it as a [B,1,C] row through the last
-                # block's dense rules instead of a [B,N,C] tensor that is zero everywhere else
-                cam = ops.index_select_relprop(cam.unsqueeze(1), self.pool.X[:, :1], 0)
-                cam = self.blocks[-1].relprop_cls_only(cam, **kwargs)
-                rest = list(self.blocks)[:-1]
-            else:
-                cam = self.pool.relprop(cam.unsqueeze(1), **kwargs)
-                rest = list(self.blocks)
-            for blk in reversed(rest):
-                cam = blk.relprop(cam, **kwargs)
+            prune = self.prune_below_start_layer and method in ("transformer_attribution", "grad")
+            stop_at = self.blocks[start_layer].attn if prune else None
+            if stop_at is not None:
+                stop_at._stop_after_attn_cam = True
+            try:
+                cam = self.head.relprop(cam, **kwargs)
+                if self.exploit_cls_sparsity and isinstance(self.head, nn.Linear):
+                    # pool.relprop puts relevance on the class token only: keep it as a [B,1,C] row through the last
+                    # block's dense rules instead of a [B,N,C] tensor that is zero everywhere else
+                    cam = ops.index_select_relprop(cam.unsqueeze(1), self.pool.X[:, :1], 0)
+                    cam = self.blocks[-1].relprop_cls_only(cam, **kwargs)
+                    rest = list(self.blocks)[:-1]
+                else:
+                    cam = self.pool.relprop(cam.unsqueeze(1), **kwargs)
+                    rest = list(self.blocks)
+                for blk in reversed(rest):
+                    cam = blk.relprop(cam, **kwargs)
+            except L.StopRelprop:
+                cam = None
+            finally:
+                if stop_at is not None:
+                    stop_at._stop_after_attn_cam = False
 
             hook = getattr(self, "_before_tail", None)    # LRP(overlap_backward=True): join with the backward pass here
             if hook is not None:
@@ -317,11 +334,12 @@ def make_vit_module(L):
 
             if method in ("transformer_attribution", "grad"):
                 # ViT_LRP.py:357-369: per block mean_h max(grad * attn_cam, 0), then rollout, row 0
-                first = self.blocks[0].attn.get_attn_cam()
+                first = self.blocks[-1].attn.get_attn_cam()
                 Bn, _, N, _ = first.shape
                 stack = torch.empty((len(self.blocks), Bn, N, N), dtype=first.dtype, device=first.device)
                 for i, blk in enumerate(self.blocks):
-                    ops.gradcam_headmean(blk.attn.get_attn_gradients(), blk.attn.get_attn_cam(), out=stack[i])
+                    if i >= start_layer or not prune:       # (the rollout reads layers >= start_layer only)
+                        ops.gradcam_headmean(blk.attn.get_attn_gradients(), blk.attn.get_attn_cam(), out=stack[i])
                 joint = ops.rollout(stack, start_layer=start_layer, normalise=False)
                 return joint[:, 0, 1:]
 
