@@ -45,7 +45,8 @@ def enable_tuned_gemms(path=None, tune=False) -> bool:
     whole generate_LRP step).  This loads the committed selection for gfx950 (tuning/tunableop_gfx950.csv, keyed by
     GEMM shape and validated against the PyTorch / rocBLAS / hipBLASLt versions; unknown shapes keep the default
     kernel).  ``tune=True`` additionally tunes shapes the file does not hold (seconds per shape, then written back to
-    ``path``).  Returns False when TunableOp is unavailable."""
+    ``path``).  Returns False when TunableOp is unavailable or the file does not match this PyTorch / rocBLAS /
+    hipBLASLt build (PyTorch's default kernels are then left in place)."""
     import os
     import torch
     try:
@@ -59,6 +60,7 @@ def enable_tuned_gemms(path=None, tune=False) -> bool:
     tunable.enable(True)
     tunable.tuning_enable(bool(tune))
     tunable.set_filename(path, insert_device_ordinal=False)
-    if os.path.exists(path):
-        tunable.read_file(path)
-    return True
+    loaded = bool(os.path.exists(path) and tunable.read_file(path))   # False: validators (library versions) differ
+    if not loaded and not tune:
+        tunable.enable(False)                                           # nothing to apply: leave PyTorch's default
+    return loaded or bool(tune)
