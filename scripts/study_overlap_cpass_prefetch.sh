@@ -1,5 +1,6 @@
 #!/bin/bash
-# C-pass prefetch-distance study + relprop-beside-backward overlap, one trip.
+# C-pass prefetch-distance study (the TE_CPASS_PF variant it toggles was removed after this study: negative result)
+# + relprop-beside-backward overlap, one trip.
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" >/dev/null 2>&1
 {
