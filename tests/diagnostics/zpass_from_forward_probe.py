@@ -1,5 +1,13 @@
-import sys, torch
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+"""CPU diagnostic (test infrastructure; imports oracle/): how far does the map move when Linear.relprop's Z is derived
+from the forward output, vs a K-permutation of the two-product form, vs fp64?  -> profiles/r01_zpass_from_forward_probe.log"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gpu_util import map_stats
 from oracle import relprop_oracle as O
 from oracle.model_cache import vit_cache_from_model

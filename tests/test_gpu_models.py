@@ -20,7 +20,7 @@ NORM_TOL = 1e-3         # min-max-normalised map, same cached inputs
 REL_TOL = 2e-3
 # Comparisons across DIFFERENT producers (GPU rocBLAS forward/backward, or a CPU forward on another host, vs the
 # build container's CPU that made tests/golden/*): LRP divides by near-zero mixed-sign sums, so rounding-level
-# producer differences are amplified chaotically on random-init models -- scripts/sensitivity_probe.py shows
+# producer differences are amplified chaotically on random-init models -- tests/diagnostics/sensitivity_probe.py shows
 # 1-ulp noise on the cached producer tensors moving the oracle's own ViT-B map by up to O(1) relative
 # (DESIGN.md section 4).  Those comparisons therefore assert only the raw north-star bar and RECORD the rest.
 LOOSE = dict(norm_tol=float("inf"), rel_tol=float("inf"))
