@@ -188,7 +188,8 @@ int te_gradcam_headmean_f32(const float* grad, const float* cam, float* out,
  * replaces compute_rollout_attention, ViT_LRP.py:38-49 (flags = 0) and ExplanationGenerator.py:7-18
  * (TE_ROLLOUT_NORMALISE), plus the CLS fix-up ExplanationGenerator.py:58 (TE_ROLLOUT_CLS_FIXUP:
  * joint[b,0,0] = min_j joint[b,0,j]).  cams [L,B,N,N] -> joint [B,N,N]:
- *   M_l = cams_l + I (/ rowsum) ; J = M_start ; J = M_i J for i = start+1 .. L-1. */
+ *   M_l = cams_l + I (/ rowsum) ; J = M_start ; J = M_i J for i = start+1 .. L-1.
+ * The (N x N)(N x N) products run on fp32 MFMA tiles; OR TE_IMPL_SIMPLE into `flags` for the plain fmaf kernel. */
 size_t te_rollout_workspace_bytes(int64_t L, int64_t B, int64_t N);
 int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
                    int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream);

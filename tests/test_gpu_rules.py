@@ -293,10 +293,13 @@ def test_attention_rules_batch_independent():
 
 
 # ------------------------------------------------------------------------------------------ rollout
-@pytest.mark.parametrize("L,B,N,start", [(4, 2, 50, 0), (12, 2, 197, 1), (3, 1, 197, 2), (5, 3, 64, 4)])
+@pytest.mark.parametrize("simple", [False, True], ids=["mfma", "simple"])
+@pytest.mark.parametrize("L,B,N,start", [(4, 2, 50, 0), (12, 2, 197, 1), (3, 1, 197, 2), (5, 3, 64, 4), (4, 2, 577, 1),
+                                         (3, 2, 512, 0), (3, 1, 1, 0)])
 @pytest.mark.parametrize("normalise", [False, True])
-def test_rollout(L, B, N, start, normalise):
+def test_rollout(L, B, N, start, normalise, simple):
     from transformer_explainability_amd import ops
+    set_impl(simple)
     cams = rnd((L, B, N, N), 41).abs() * 0.01
     got = ops.rollout(cams.to(dev()), start_layer=start, normalise=normalise)
     ref = O.rollout(list(cams), start, normalise=normalise)

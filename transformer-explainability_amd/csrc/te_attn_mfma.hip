@@ -367,7 +367,57 @@ __global__ __launch_bounds__(kThreads) void z_qk_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Rollout chain step (te_rollout.hip): C[b] = A[b] Bm[b], all [N,N] row-major, on the same 64 x 64 MFMA tiles --
+// A stripe K-contiguous, Bm chunk k-major; N need not be a multiple of anything (dword-aligned 16-B accesses).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void rollout_bmm_mfma_kernel(const float* __restrict__ A,
+                                                                    const float* __restrict__ Bm,
+                                                                    float* __restrict__ C, int N, int nt) {
+  __shared__ __attribute__((aligned(16))) float At[TS * TS];
+  __shared__ __attribute__((aligned(16))) float Bt[TS * TS];
+  const int b = blockIdx.x / (nt * nt), t = blockIdx.x % (nt * nt);
+  const int row0 = (t / nt) * TS, col0 = (t % nt) * TS;
+  const int rows_valid = min(TS, N - row0), cols_valid = min(TS, N - col0);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, kh = lane >> 5;
+  const float* a_b = A + ((int64_t)b * N + row0) * N;
+  const float* b_b = Bm + (int64_t)b * N * N + col0;
+  f32x16 acc;
+  zero(acc);
+  TileRegs ta, tb;
+  load_tile(ta, a_b, N, rows_valid, min(TS, N));
+  load_tile(tb, b_b, N, min(TS, N), cols_valid);
+  for (int c = 0; c < nt; ++c) {
+    __syncthreads();
+    store_tile(At, ta);              // rows = output rows (m), K = k of this chunk
+    store_tile(Bt, tb);              // [k][n]
+    __syncthreads();
+    if (c + 1 < nt) {
+      const int kv = min(TS, N - (c + 1) * TS);
+      load_tile(ta, a_b + (c + 1) * TS, N, rows_valid, kv);
+      load_tile(tb, b_b + (int64_t)(c + 1) * TS * N, N, kv, cols_valid);
+    }
+    if ((wm * 32) < rows_valid && (wn * 32) < cols_valid) mma64<false, true>(acc, At, Bt, wm, wn, lr, kh);
+  }
+  const int gj = col0 + wn * 32 + lr;
+  if (gj < N) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int gi = row0 + wm * 32 + crow(e, kh);
+      if (gi < N) C[((int64_t)b * N + gi) * N + gj] = acc[e];
+    }
+  }
+}
+
 }  // namespace
+
+int rollout_bmm_launch(const float* A, const float* Bm, float* C, int64_t B, int64_t N, hipStream_t stream) {
+  const int64_t nt = (N + TS - 1) / TS;
+  if (B * nt * nt > 0x7fffffff || N > (1 << 20)) return TE_ERR_UNSUPPORTED;
+  rollout_bmm_mfma_kernel<<<dim3((unsigned)(B * nt * nt)), dim3(kThreads), 0, stream>>>(A, Bm, C, (int)N, (int)nt);
+  return TE_OK;
+}
 
 bool av_supported(int64_t N, int64_t D) { return D == TS && N >= 1 && N <= (1 << 20); }
 bool qk_supported(int64_t N, int64_t D) { return D == TS && N >= 1 && N <= (1 << 20); }

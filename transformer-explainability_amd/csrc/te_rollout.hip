@@ -5,9 +5,15 @@
 //
 // prep kernel: one wave per row builds M_l in the workspace (adds the identity, optional row
 // normalisation with the row sum taken in index order like torch.sum over the last dim).
-// chain kernel: batched (N x N)(N x N) fp32 product, 64 x 64 output tile per 256-thread block staged
-// through LDS in 16-deep K slices, 4 x 4 register micro-tile per thread, k-ordered fmaf chains.
+// chain kernel: batched (N x N)(N x N) fp32 product on v_mfma_f32_32x32x2_f32, 64 x 64 output tile per block
+// (rollout_bmm_mfma_kernel in te_attn_mfma.hip, the tile machinery of the attention rules).  The plain kernel below
+// (LDS-staged 16-deep K slices, 4 x 4 register micro-tile per thread, k-ordered fmaf chains) is its cross-check,
+// selected by TE_IMPL_SIMPLE in `flags`.
 #include "te_common.h"
+
+namespace te_attn_mfma {
+int rollout_bmm_launch(const float* A, const float* Bm, float* C, int64_t B, int64_t N, hipStream_t stream);
+}
 
 namespace {
 
@@ -144,7 +150,8 @@ extern "C" int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer,
     for (int64_t s = 0; s < steps; ++s) {
       const int64_t i = start_layer + 1 + s;
       float* dst = ((steps - 1 - s) % 2 == 0) ? joint : tmp;
-      rollout_bmm_kernel<<<grid, blk, 0, stream>>>(M + i * mat, cur, dst, N);
+      if ((flags & TE_IMPL_SIMPLE) || te_attn_mfma::rollout_bmm_launch(M + i * mat, cur, dst, B, N, stream) != TE_OK)
+        rollout_bmm_kernel<<<grid, blk, 0, stream>>>(M + i * mat, cur, dst, N);
       cur = dst;
     }
   }

@@ -283,7 +283,8 @@ def rollout(cams: Tensor, start_layer: int = 0, normalise: bool = False, cls_fix
     cams = _c(cams)
     L, B, N, _ = cams.shape
     joint = torch.empty((B, N, N), dtype=torch.float32, device=cams.device)
-    flags = (TE_ROLLOUT_NORMALISE if normalise else 0) | (TE_ROLLOUT_CLS_FIXUP if cls_fixup else 0)
+    flags = (TE_ROLLOUT_NORMALISE if normalise else 0) | (TE_ROLLOUT_CLS_FIXUP if cls_fixup else 0) | \
+        (TE_IMPL_SIMPLE if FORCE_SIMPLE else 0)
     with _on_device(cams) as lib:
         ws = _ws(lib.te_rollout_workspace_bytes(L, B, N), cams)
         _lib.check(lib.te_rollout_f32(_ptr(cams), L, int(start_layer), B, N, flags, _ptr(joint), _ptr(ws), ws.numel(),
