@@ -326,7 +326,22 @@ __global__ __launch_bounds__(kThreads) void headmean_kernel(
   for (int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * VEC; e < NN; e += stride) {
     if (VEC == 4 && e + 3 < NN) {
       f32x4_u acc = {0.f, 0.f, 0.f, 0.f};
-      for (int64_t h = 0; h < H; ++h) {
+      int64_t h = 0;
+      // four heads = eight independent 16-B loads in flight per thread (H is a run-time value: the plain loop
+      // waits for each pair before issuing the next); the heads are still added in index order
+      for (; h + 4 <= H; h += 4) {
+        f32x4_u gv[4], cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          gv[u] = ld<f32x4_u>(g + (h + u) * NN + e);
+          cv[u] = ld<f32x4_u>(c + (h + u) * NN + e);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] = acc[k] + fmaxf(gv[u][k] * cv[u][k], 0.0f);
+      }
+      for (; h < H; ++h) {
         const f32x4_u gv = ld<f32x4_u>(g + h * NN + e), cv = ld<f32x4_u>(c + h * NN + e);
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = acc[k] + fmaxf(gv[k] * cv[k], 0.0f);
