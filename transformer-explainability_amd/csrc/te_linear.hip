@@ -573,6 +573,28 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
   if (interior) k_loop(std::true_type{});
   else k_loop(std::false_type{});
 
+  if constexpr (MODE == 0 && !ACCUM) {
+    if (interior) {
+      // interior tiles: the 16 X values of a 32x32 block are all requested before the first is used (the guarded loop
+      // below issues each load behind a bounds test and in front of a store)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int64_t gc = tc.col0 + wn * WN + ni * 32 + lr;
+          const int64_t gr0 = tc.row0 + wm * WM + mi * 32 + 4 * kh;
+          float xv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) xv[e] = X[(gr0 + (e & 3) + 8 * (e >> 2)) * Nn + gc];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float xp = fmaxf(xv[e], 0.0f), xn = fminf(xv[e], 0.0f);
+            out[(gr0 + (e & 3) + 8 * (e >> 2)) * Nn + gc] = scale * (xp * acc[0][mi][ni][e] + xn * acc[1][mi][ni][e]);
+          }
+        }
+      return;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
