@@ -171,7 +171,16 @@ __global__ __launch_bounds__(kThreads) void av_row_kernel(
       zero(g);
       mma64<false, false>(g, St, Vt, wm, wn, lr, kh);
       const int gj = c * TS + wn * 32 + lr;
-      if (gj < N) {
+      if (rows_valid == TS && kc == TS) {
+        // full tile: all 16 attention values of the block requested before the first is used (the guarded form below
+        // issues every load behind its own bounds test)
+        const int64_t base = ((int64_t)bh * N + row0 + wm * 32) * N + gj;
+        float av[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) av[e] = attn[base + (int64_t)crow(e, kh) * N];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cam_attn[base + (int64_t)crow(e, kh) * N] = (av[e] * g[e]) * scale;
+      } else if (gj < N) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int gi = row0 + wm * 32 + crow(e, kh);
