@@ -77,6 +77,14 @@ struct TileRegs {
 };
 __device__ __forceinline__ void load_tile(TileRegs& t, const float* __restrict__ src, int64_t ld, int rows_valid,
                                           int cols_valid) {
+  if (rows_valid == TS && cols_valid == TS) {     // full tile (block-uniform): four unguarded loads issued together
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      t.v[i] = *reinterpret_cast<const f32x4_u*>(src + (int64_t)(idx >> 4) * ld + ((idx & 15) << 2));
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = threadIdx.x + i * kThreads;
@@ -144,6 +152,26 @@ __global__ __launch_bounds__(kThreads) void av_row_kernel(
   TileRegs tv;
   load_tile(tv, v_bh, vs.sn, min(TS, N), TS);
   // S = sd(R, Z) for this stripe: into LDS (A operand of S v^T) and the workspace (cam_v kernel)
+  if (rows_valid == TS) {            // full stripe: the eight loads go out before the first division
+    f32x4 r[4], z[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      const int row = idx >> 4, c = (idx & 15) << 2;
+      r[i] = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(row0 + row) * rs.sn + c);
+      z[i] = *reinterpret_cast<const f32x4_u*>(Z + ((int64_t)bh * N + row0 + row) * TS + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * kThreads;
+      const int row = idx >> 4, c = (idx & 15) << 2;
+      f32x4 s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = te_sd(r[i][e], z[i][e]);
+      *reinterpret_cast<f32x4_u*>(Sws + ((int64_t)bh * N + row0 + row) * TS + c) = s;
+      *reinterpret_cast<f32x4*>(St + swz(row, idx & 15)) = s;
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = threadIdx.x + i * kThreads;
@@ -231,6 +259,14 @@ __global__ __launch_bounds__(kThreads) void col_kernel(
   const float* x_bh = X + (int64_t)b * xs.sb + (int64_t)h * xs.sh;
   float* o_bh = out + (int64_t)b * os.sb + (int64_t)h * os.sh;
   const int d = wn * 32 + lr;
+  if (cols_valid == TS) {            // full tile: the 16 X values are requested together
+    float xv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xv[e] = x_bh[(int64_t)(col0 + wm * 32 + crow(e, kh)) * xs.sn + d];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_bh[(int64_t)(col0 + wm * 32 + crow(e, kh)) * os.sn + d] = (xv[e] * acc[e]) * scale;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int j = col0 + wm * 32 + crow(e, kh);
@@ -262,6 +298,27 @@ __global__ __launch_bounds__(kThreads) void qk_row_kernel(
   // registers until the LDS tile is free, and written to the workspace for the cam_k kernel
   auto s_chunk = [&](TileRegs& ts, int c) __attribute__((always_inline)) {
     const int kc = min(TS, N - c * TS);
+    if (rows_valid == TS && kc == TS) {            // full tile: the eight loads go out before the first division
+      f32x4 r[4], z[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        const int64_t off = nn0 + (int64_t)(idx >> 4) * N + c * TS + ((idx & 15) << 2);
+        r[i] = *reinterpret_cast<const f32x4_u*>(Rnn + off);
+        z[i] = *reinterpret_cast<const f32x4_u*>(Z + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + i * kThreads;
+        const int64_t off = nn0 + (int64_t)(idx >> 4) * N + c * TS + ((idx & 15) << 2);
+        f32x4 sv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[e] = te_sd(r[i][e], z[i][e]);
+        *reinterpret_cast<f32x4_u*>(Sws + off) = sv;
+        ts.v[i] = sv;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = threadIdx.x + i * kThreads;
@@ -296,6 +353,14 @@ __global__ __launch_bounds__(kThreads) void qk_row_kernel(
   }
   float* o_bh = cam_q + (int64_t)b * cs.sb + (int64_t)h * cs.sh;
   const int d = wn * 32 + lr;
+  if (rows_valid == TS) {            // full stripe: the 16 q values are requested together
+    float qv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) qv[e] = q_bh[(int64_t)(row0 + wm * 32 + crow(e, kh)) * qs.sn + d];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_bh[(int64_t)(row0 + wm * 32 + crow(e, kh)) * cs.sn + d] = (qv[e] * accq[e]) * scale;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int gi = row0 + wm * 32 + crow(e, kh);
