@@ -351,7 +351,35 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
         mma_group(f1);
         __builtin_amdgcn_sched_barrier(0);
       };
-      for (int kt = 0; kt < nk; kt += 2) {
+      // steady state: four K-steps of straight-line code per trip, every refill unconditional.  (hipcc's waitcnt
+      // insertion loses the age order of in-flight loads across a loop back-edge and then drains ALL of them before
+      // the first ds_write -- inside the straight-line stretch it knows that the stage being published is the older
+      // one and waits vmcnt(4) only, which is what makes the prefetch distance really 2.)
+      auto steady = [&](int kt, int cur, f32x4 (&xa)[BM / 32], f32x4 (&xb)[BN / 32]) __attribute__((always_inline)) {
+        read_frag(f1, cur, 1);
+        mma_group(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f0, cur, 2);
+        mma_group(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f1, cur, 3);
+        mma_group(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        abs_store(cur ^ 1, xa, xb);
+        __syncthreads();
+        load_into(kt + 3, xa, xb);
+        read_frag(f0, cur ^ 1, 0);
+        mma_group(f1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      int kt = 0;
+      for (; kt + 7 <= nk; kt += 4) {          // kt + 3 + 3 < nk for all four steps
+        steady(kt, 0, ra, rb);
+        steady(kt + 1, 1, qa, qb);
+        steady(kt + 2, 0, ra, rb);
+        steady(kt + 3, 1, qa, qb);
+      }
+      for (; kt < nk; kt += 2) {
         body(kt, 0, ra, rb);
         if (kt + 1 < nk) body(kt + 1, 1, qa, qb);
       }
