@@ -31,6 +31,12 @@
 // blockIdx -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous run of tiles (n fastest), so blocks that
 // share an X/S row panel share an L2.
 //
+// The one-product Z-pass (K1f) has half the MFMAs per K-step and is bound by the latency of its global loads: it runs
+// a two-stage REGISTER pipeline (the loads of K-step kt+3 go out right after the barrier that published kt+1) written
+// as four straight-line K-steps per loop trip -- hipcc's waitcnt insertion drains every in-flight load at a loop
+// back-edge, straight-line code lets it keep the newer stage in flight -- prefers 64x64 tiles (5 blocks per CU), and
+// requests all R / Y values of a 32x32 block before the first use in its epilogue.
+//
 // fp32 MFMA runs at 1/16 of the bf16 rate, so LDS and L2 bandwidth are idle at every tile size (8 B/clk/CU of LDS
 // reads against 256); what the tile choice trades is granularity (tiles per CU in the last round) against the
 // number of co-resident waves that cover barriers and epilogues.  DESIGN.md section 3 has the ablation study.
