@@ -185,7 +185,7 @@ def main():
         torch.distributed.barrier()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     te._lib.require_device()
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", int(os.environ.get("TE_DEVICE_OVERRIDE", local)))   # (override: test rigs with one GPU)
     torch.cuda.set_device(dev)
     tuned = False
     if args.tuned_gemms == "on":
@@ -289,12 +289,12 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         line = {
-            "metric": "relevance maps/sec (ViT-B/16 224^2, batch 64 per GPU, generate_LRP transformer_attribution)",
+            "metric": f"relevance maps/sec (ViT-B/16 224^2, batch {B} per GPU, generate_LRP transformer_attribution)",
             "value": value, "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ViT-B/16 224^2 batch 64 on 1xMI355X: stock fwd + attn-grad bwd + fp32 relprop/"
-                                   "head-mean/rollout HIP kernels (BASELINE.json configs[1])",
+            "config": {"workload": f"ViT-B/16 224^2 batch {B} per GPU on {world}xMI355X: stock fwd + attn-grad bwd + fp32 "
+                                   "relprop/head-mean/rollout HIP kernels (BASELINE.json configs[1], sharded by sample)",
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": 197, "blocks": 12,
                        "start_layer": args.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "streams": args.streams, "steps_in_flight": args.inflight,

@@ -24,9 +24,10 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+        # "nccl" IS RCCL on ROCm; TE_DIST_BACKEND=gloo lets several ranks share ONE GPU (test rigs: RCCL refuses that)
+        backend = os.environ.get("TE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(int(os.environ.get("TE_DEVICE_OVERRIDE", local)))
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -52,6 +53,8 @@ def gather_maps(local_maps: torch.Tensor, n_items: int) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local_maps
     world = dist.get_world_size()
+    if local_maps.is_cuda and dist.get_backend() == "gloo":      # gloo has no device all_gather: stage through the host
+        return gather_maps(local_maps.cpu(), n_items).to(local_maps.device)
     counts = [shard_range(n_items, r, world) for r in range(world)]
     max_n = max(hi - lo for lo, hi in counts)
     M = local_maps.shape[1:]
