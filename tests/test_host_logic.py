@@ -227,3 +227,33 @@ def test_dropin_import_paths(golden_vit_tiny):
         sys.path.remove(d)
         for k in [k for k in sys.modules if k.split(".")[0] in ("modules", "baselines", "BERT_explainability")]:
             del sys.modules[k]
+
+
+def test_split_qkv_matches_the_permuted_views_and_their_gradient():
+    """vit.split_qkv (one autograd node, no zero-fill / accumulate in backward) == the reference's permuted views
+    (ViT_LRP.py:135-136), values and gradients, also when only some of q / k / v receive a gradient."""
+    from transformer_explainability_amd.vit import split_qkv
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 5, 3 * 4 * 8), generator=g, requires_grad=True)
+    w = torch.randn((2, 4, 5, 8), generator=g)
+    q, k, v = split_qkv(x, 4)
+    ref = x.view(2, 5, 3, 4, 8).permute(2, 0, 3, 1, 4)
+    assert all(t.is_contiguous() for t in (q, k, v))
+    assert torch.equal(q, ref[0]) and torch.equal(k, ref[1]) and torch.equal(v, ref[2])
+    (ga,) = torch.autograd.grad((q * w).sum() + (k * 2).sum() + (v * w * 3).sum(), x)
+    (gb,) = torch.autograd.grad((ref[0] * w).sum() + (ref[1] * 2).sum() + (ref[2] * w * 3).sum(), x)
+    assert torch.equal(ga, gb)
+    (gk,) = torch.autograd.grad((split_qkv(x, 4)[1] * w).sum(), x)
+    (gr,) = torch.autograd.grad((ref[1] * w).sum(), x)
+    assert torch.equal(gk, gr)
+
+
+def test_cpu_only_hosts_get_no_silent_fallback():
+    """No GPU here: the tuned-GEMM switch reports False, and the device ops refuse CPU tensors loudly."""
+    import transformer_explainability_amd as te
+    from transformer_explainability_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    assert te.enable_tuned_gemms() is False
+    with pytest.raises(te.TeError):
+        ops.clone_relprop((torch.zeros(1, 2, 4), torch.zeros(1, 2, 4)), torch.ones(1, 2, 4))
