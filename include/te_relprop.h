@@ -46,7 +46,7 @@ enum {
 
 enum { TE_VARIANT_OURS = 0, TE_VARIANT_LRP = 1, TE_IMPL_SIMPLE = 0x100 };
 
-enum { TE_ROLLOUT_NORMALISE = 1, TE_ROLLOUT_CLS_FIXUP = 2 };
+enum { TE_ROLLOUT_NORMALISE = 1, TE_ROLLOUT_CLS_FIXUP = 2, TE_ROLLOUT_ROW0 = 4 };
 
 /* library version (major*10000 + minor*100 + patch) and status strings */
 int te_version(void);
@@ -92,6 +92,18 @@ int te_linear_zpass_fwd_f32(const float* R, const float* X, const float* W, cons
 int te_linear_relprop_fwd_f32(const float* R, const float* X, const float* W, const float* Y, const float* bias,
                               float* out, int64_t T, int64_t in_f, int64_t out_f,
                               void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* The same with a DEFERRED per-sample factor on the relevance operand: row t of R enters the rule as
+ * R[t,:] * r_scale[(t / rows_per_sample) * r_scale_stride] (the fp32 product Add.relprop's rescale would have stored,
+ * layers_ours.py:117-118) -- the consumer side of te_add_relprop_deferred_f32.  r_scale == NULL: plain R. */
+int te_linear_zpass_fwd_scaled_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
+                                   int64_t rows_per_sample, const float* X, const float* W, const float* Y,
+                                   const float* bias, float* S, int64_t T, int64_t in_f, int64_t out_f,
+                                   te_stream_t stream);
+int te_linear_relprop_fwd_scaled_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
+                                     int64_t rows_per_sample, const float* X, const float* W, const float* Y,
+                                     const float* bias, float* out, int64_t T, int64_t in_f, int64_t out_f,
+                                     void* ws, size_t ws_bytes, te_stream_t stream);
 
 /* ---- a4  einsum / MatMul relprop (RelPropSimple) ---------------------------------------------
  * replaces modules/layers_ours.py:48-60,122-127 and BERT_explainability/modules/layers_ours.py:89-91
@@ -156,6 +168,16 @@ int te_add_relprop_f32(const float* R, const float* X0, const float* X1, float* 
                        int64_t B, int64_t n, int64_t x1_batch_stride, int variant,
                        void* ws, size_t ws_bytes, te_stream_t stream);
 
+/* Add.relprop, variant ours, with the per-sample rescale DEFERRED to the consumers: ONE streaming pass (the rule's
+ * algorithmic 5 n floats per sample) writes a = X0.S and b = X1.S unscaled and fac [B,2] = {fa, fb} per sample, where
+ * te_add_relprop_f32 would have stored out0 = a*fa, out1 = b*fb (layers_ours.py:117-118).  The consumers take the
+ * factor with the operand and form the identical product in registers: te_clone_relprop_scaled_f32,
+ * te_linear_relprop_fwd_scaled_f32.  Workspace: te_add_relprop_deferred_workspace_bytes. */
+size_t te_add_relprop_deferred_workspace_bytes(int64_t B, int64_t n);
+int te_add_relprop_deferred_f32(const float* R, const float* X0, const float* X1, float* a, float* b, float* fac,
+                                int64_t B, int64_t n, int64_t x1_batch_stride,
+                                void* ws, size_t ws_bytes, te_stream_t stream);
+
 /* Broadcast-operand Add of BERT self-attention (BERT.py:342,386-388): X0 = scaled scores
  * [B,H,N,N], X1 = extended mask [B,1,1,N] given as mask [B,N].  out0 [B,H,N,N] (relevance of the
  * scores); out1 [B,N] (relevance of the mask, discarded by the reference) may be NULL.
@@ -171,6 +193,13 @@ int te_add_bcast_relprop_f32(const float* R, const float* X0, const float* mask,
  * NULL (num = 2: ViT_LRP.py:194-196, BERT.py:247,527) or not (num = 3: BERT.py:407). n elements. */
 int te_clone_relprop_f32(const float* R0, const float* R1, const float* R2, const float* X,
                          float* out, int64_t n, te_stream_t stream);
+
+/* Clone.relprop on [B,n] operands whose relevance inputs carry deferred per-sample factors: R_i enters as
+ * R_i[b,:] * s_i[b * s_i_stride]; s_i == NULL means no factor (R2 == NULL: two aliases). */
+int te_clone_relprop_scaled_f32(const float* R0, const float* s0, int64_t s0_stride,
+                                const float* R1, const float* s1, int64_t s1_stride,
+                                const float* R2, const float* s2, int64_t s2_stride,
+                                const float* X, float* out, int64_t B, int64_t n, te_stream_t stream);
 
 /* ---- a7  IndexSelect.relprop ----------------------------------------------------------------------
  * replaces modules/layers_ours.py:129-147 for dim=1, one index (ViT_LRP.py:319,329; BERT.py:170,189).
@@ -189,8 +218,13 @@ int te_gradcam_headmean_f32(const float* grad, const float* cam, float* out,
  * (TE_ROLLOUT_NORMALISE), plus the CLS fix-up ExplanationGenerator.py:58 (TE_ROLLOUT_CLS_FIXUP:
  * joint[b,0,0] = min_j joint[b,0,j]).  cams [L,B,N,N] -> joint [B,N,N]:
  *   M_l = cams_l + I (/ rowsum) ; J = M_start ; J = M_i J for i = start+1 .. L-1.
- * The (N x N)(N x N) products run on fp32 MFMA tiles; OR TE_IMPL_SIMPLE into `flags` for the plain fmaf kernel. */
+ * The (N x N)(N x N) products run on fp32 MFMA tiles; OR TE_IMPL_SIMPLE into `flags` for the plain fmaf kernel.
+ * TE_ROLLOUT_ROW0: only row 0 of the joint matrix is produced -- what both generators consume (ViT_LRP.py:369
+ * `rollout[:, 0, 1:]`, ExplanationGenerator.py:58-59 `rollout[:, 0]`) -- as the vector chain r = e_0^T M_{L-1},
+ * r = r M_i (i = L-2 .. start): every layer matrix is read once (HBM-bound) instead of L-1-start N^3 products.
+ * `joint` is then [B,N]; the workspace query is te_rollout_row0_workspace_bytes; N <= 1024. */
 size_t te_rollout_workspace_bytes(int64_t L, int64_t B, int64_t N);
+size_t te_rollout_row0_workspace_bytes(int64_t B, int64_t N);
 int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
                    int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream);
 

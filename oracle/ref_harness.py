@@ -1,7 +1,9 @@
 """Harness that imports and runs the UNMODIFIED reference from ``/root/reference`` on CPU.
 
 TEST INFRASTRUCTURE ONLY (see oracle/relprop_oracle.py header).  ``/root/reference`` exists only
-in the build container, never on the GPU box: this module is used (a) by
+in the build container, never on the GPU box; there the harness falls back to ``oracle/_ref/``, the
+git-ignored byte-for-byte stage of the hot-path files made by ``scripts/stage_reference.py``
+(called from ``__graft_entry__.build()`` in the build container).  This module is used (a) by
 ``tests/golden/make_golden.py`` to generate the committed fixtures, (b) by CPU tests that are
 skipped when the checkout is absent, (c) by ``bench.py``'s optional ``cpu_baseline`` leg of kind
 "reference" when the checkout is present.
@@ -22,11 +24,33 @@ from contextlib import contextmanager
 
 import torch
 
-REFERENCE_ROOT = os.environ.get("TE_REFERENCE_ROOT", "/root/reference")
+_STAGE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+def _pick_root() -> str:
+    """The reference checkout: $TE_REFERENCE_ROOT, else /root/reference (build container), else the git-ignored stage
+    ``oracle/_ref/`` that scripts/stage_reference.py copies from it (what travels to the GPU box)."""
+    env = os.environ.get("TE_REFERENCE_ROOT")
+    if env:
+        return env
+    for cand in ("/root/reference", _STAGE):
+        if os.path.isdir(os.path.join(cand, "modules")):
+            return cand
+    return "/root/reference"
+
+
+REFERENCE_ROOT = _pick_root()
 
 
 def reference_available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "modules"))
+
+
+def reference_origin() -> str:
+    """'checkout' (the read-only reference tree), 'stage' (oracle/_ref) or 'absent'."""
+    if not reference_available():
+        return "absent"
+    return "stage" if os.path.abspath(REFERENCE_ROOT) == os.path.abspath(_STAGE) else "checkout"
 
 
 @contextmanager

@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a host without an MI355X skips the gpu-marked tests instead of failing 250 times with
+    'No HIP GPUs are available'.  The no-silent-fallback guarantee keeps its own CPU test
+    (test_host_logic.py::test_cpu_only_hosts_get_no_silent_fallback): the product path raises, it never computes on the host."""
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no HIP device on this host)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     """npz -> dict of torch tensors (0-d arrays stay python floats)."""
     z = np.load(os.path.join(GOLDEN, name))

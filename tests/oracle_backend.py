@@ -5,11 +5,19 @@ stride/view plumbing, generators, sharding) on a machine without a GPU.  The pro
 """
 import contextlib
 
+import torch
+
 from oracle import relprop_oracle as O
 
 
+def _plain(r):
+    """A Deferred relevance operand (unscaled tensor + per-sample factor) as the plain tensor the rule consumes."""
+    from transformer_explainability_amd import ops
+    return r.materialise() if isinstance(r, ops.Deferred) else r
+
+
 def linear_relprop(R, X, W, alpha=1.0, variant="ours", Y=None, bias=None):
-    return O.linear_relprop(R, X, W, alpha=alpha, variant=variant)     # Y / bias: a device-side shortcut only
+    return O.linear_relprop(_plain(R), X, W, alpha=alpha, variant=variant)     # Y / bias: a device-side shortcut only
 
 
 def matmul_relprop_av(R, attn, v, out_scale=1.0, cam_v_out=None, variant="ours", z=None):
@@ -35,12 +43,19 @@ def matmul_relprop_qk(R, q, k, out_scale=1.0, cam_q_out=None, cam_k_out=None, va
     return c_q, c_k
 
 
-def add_relprop(R, X0, X1, variant="ours"):
-    return O.add_relprop(R, X0, X1, variant)
+def add_relprop(R, X0, X1, variant="ours", deferred=False):
+    a, b = O.add_relprop(R, X0, X1, variant)
+    if deferred and variant == "ours":
+        # same host-side contract as the device op: (tensor, per-sample factor) pairs.  The oracle has already applied
+        # the rescale, so the factor is an exact 1 (x * 1.0f is the identity in fp32).
+        from transformer_explainability_amd import ops
+        one = torch.ones((X0.shape[0], 2), dtype=a.dtype)
+        return ops.Deferred(a, one[:, 0]), ops.Deferred(b, one[:, 1])
+    return a, b
 
 
 def clone_relprop(Rs, X):
-    return O.clone_relprop(list(Rs), X)
+    return O.clone_relprop([_plain(r) for r in Rs], X)
 
 
 def index_select_relprop(R, X, index):
@@ -55,11 +70,11 @@ def gradcam_headmean(grad, cam, out=None):
     return r
 
 
-def rollout(cams, start_layer=0, normalise=False, cls_fixup=False):
+def rollout(cams, start_layer=0, normalise=False, cls_fixup=False, row0_only=False):
     joint = O.rollout(list(cams), start_layer, normalise=normalise).clone()
     if cls_fixup:
         joint[:, 0, 0] = joint[:, 0].min(dim=-1).values
-    return joint
+    return joint[:, 0] if row0_only else joint
 
 
 def conv2d_zb_relprop(R, X, W, Y, bias=None):

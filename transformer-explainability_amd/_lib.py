@@ -21,6 +21,7 @@ TE_VARIANT_LRP = 1
 TE_IMPL_SIMPLE = 0x100
 TE_ROLLOUT_NORMALISE = 1
 TE_ROLLOUT_CLS_FIXUP = 2
+TE_ROLLOUT_ROW0 = 4
 
 _P, _I64, _F, _I, _SZ = c_void_p, c_int64, c_float, c_int, c_size_t
 
@@ -35,6 +36,8 @@ SIGNATURES = {
     "te_linear_cpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "te_linear_zpass_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "te_linear_relprop_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
+    "te_linear_zpass_fwd_scaled_f32": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "te_linear_relprop_fwd_scaled_f32": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     "te_matmul_relprop_av_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64]),
     "te_matmul_relprop_av_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
                                       _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
@@ -47,9 +50,12 @@ SIGNATURES = {
                                       _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_add_relprop_workspace_bytes": (_SZ, [_I64, _I64]),
     "te_add_relprop_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _SZ, _P]),
+    "te_add_relprop_deferred_workspace_bytes": (_SZ, [_I64, _I64]),
+    "te_add_relprop_deferred_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     "te_add_bcast_relprop_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_add_bcast_relprop_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _SZ, _P]),
     "te_clone_relprop_f32": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
+    "te_clone_relprop_scaled_f32": (_I, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _P]),
     "te_index_select_relprop_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),
     "te_gradcam_headmean_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "te_heatmap_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
@@ -59,6 +65,7 @@ SIGNATURES = {
     "te_perturb_workspace_bytes": (_SZ, [_I64, _I64]),
     "te_perturb_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _I64, _P, _P, _P, _SZ, _P]),
     "te_rollout_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
+    "te_rollout_row0_workspace_bytes": (_SZ, [_I64, _I64]),
     "te_rollout_f32": (_I, [_P, _I64, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
 }
 

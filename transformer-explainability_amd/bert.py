@@ -157,7 +157,8 @@ def make_bert_module(L):
             return self.LayerNorm(self.add([self.dropout(self.dense(hidden_states)), input_tensor]))
 
         def relprop(self, cam, **kwargs):        # BERT.py:427-434
-            cam1, cam2 = self.add.relprop(cam, **kwargs)
+            # (deferred: the Add's per-sample rescale rides with cam1 / cam2 into dense.relprop / the Clone rule)
+            cam1, cam2 = self.add.relprop(cam, deferred=True, **kwargs)
             return self.dense.relprop(cam1, **kwargs), cam2
 
     class BertAttention(nn.Module):
@@ -201,7 +202,7 @@ def make_bert_module(L):
             return self.LayerNorm(self.add([self.dropout(self.dense(hidden_states)), input_tensor]))
 
         def relprop(self, cam, **kwargs):        # BERT.py:474-487
-            cam1, cam2 = self.add.relprop(cam, **kwargs)
+            cam1, cam2 = self.add.relprop(cam, deferred=True, **kwargs)
             return self.dense.relprop(cam1, **kwargs), cam2
 
     class BertLayer(nn.Module):
@@ -235,15 +236,19 @@ def make_bert_module(L):
             cls = lambda t: t[:, :1]                                             # noqa: E731
             lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,     # noqa: E731
                                                   Y=cls(m.Y), bias=m.bias)
-            c1, c2 = ops.add_relprop(cam_cls, cls(self.output.add.X[0]), cls(self.output.add.X[1]), variant=var)
+            dfr = ops.USE_DEFERRED_ADD
+            c1, c2 = ops.add_relprop(cam_cls, cls(self.output.add.X[0]), cls(self.output.add.X[1]), variant=var,
+                                     deferred=dfr)
             c1 = lin(lin(c1, self.output.dense), self.intermediate.dense)
             cam = ops.clone_relprop((c1, c2), cls(self.clone.X))
             att = self.attention
-            a1, a2 = ops.add_relprop(cam, cls(att.output.add.X[0]), cls(att.output.add.X[1]), variant=var)
+            a1, a2 = ops.add_relprop(cam, cls(att.output.add.X[0]), cls(att.output.add.X[1]), variant=var, deferred=dfr)
             a1 = lin(a1, att.output.dense)
             B, N, C = att.clone.X.shape
             dense = torch.zeros((2, B, N, C), dtype=a1.dtype, device=a1.device)
             dense[0, :, 0] = a1[:, 0]
+            if isinstance(a2, ops.Deferred):
+                a2 = a2.materialise()
             dense[1, :, 0] = a2[:, 0]
             cam1 = att.self.relprop(dense[0], **kwargs)
             return att.clone.relprop((cam1, dense[1]), **kwargs)

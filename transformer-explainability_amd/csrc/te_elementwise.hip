@@ -4,6 +4,8 @@
 // order (bit-reproducible, no atomics), and evaluate safe_divide exactly like the reference.
 //
 // Build flags matter: -ffp-contract=off (the reference rounds every product and sum separately).
+#include <stdlib.h>
+
 #include "te_common.h"
 
 namespace {
@@ -61,6 +63,60 @@ __global__ __launch_bounds__(kThreads) void add_sums_kernel(
   }
 }
 
+// Deferred form (te_add_relprop_deferred_f32): the same pass also stores the UNSCALED a = X0.S and b = X1.S; the
+// per-sample factors are applied by whoever reads them next (Clone / the Linear Z-pass epilogue multiply R by the
+// sample's factor -- the identical fp32 product the apply pass would have stored), so Add.relprop moves its
+// algorithmic 5 n floats per sample exactly once.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void add_deferred_kernel(
+    const float* __restrict__ R, const float* __restrict__ X0, const float* __restrict__ X1,
+    float* __restrict__ a_out, float* __restrict__ b_out, double* __restrict__ partial, int64_t n, int64_t x1_bs,
+    int64_t chunk) {
+  __shared__ double smem[3 * (kThreads / 64)];
+  const int64_t b = blockIdx.y;
+  const int64_t start = (int64_t)blockIdx.x * chunk;
+  const int64_t end = min(n, start + chunk);
+  const float* r = R + b * n;
+  const float* x0 = X0 + b * n;
+  const float* x1 = X1 + b * x1_bs;
+  float* o0 = a_out + b * n;
+  float* o1 = b_out + b * n;
+  double sa = 0.0, sb = 0.0, sr = 0.0;
+  for (int64_t i = start + (int64_t)threadIdx.x * VEC; i < end; i += (int64_t)kThreads * VEC) {
+    if constexpr (VEC == 4) {
+      const f32x4 rv = ld<f32x4>(r + i), av = ld<f32x4>(x0 + i), bv = ld<f32x4>(x1 + i);
+      f32x4 oa, ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = te_sd(rv[e], av[e] + bv[e]);
+        oa[e] = av[e] * s;
+        ob[e] = bv[e] * s;
+        sa += (double)oa[e];
+        sb += (double)ob[e];
+        sr += (double)rv[e];
+      }
+      st<f32x4>(o0 + i, oa);
+      st<f32x4>(o1 + i, ob);
+    } else {
+      const float rv = r[i], av = x0[i], bv = x1[i];
+      const float s = te_sd(rv, av + bv);
+      const float a = av * s, bb = bv * s;
+      o0[i] = a;
+      o1[i] = bb;
+      sa += (double)a;
+      sb += (double)bb;
+      sr += (double)rv;
+    }
+  }
+  te_block_sum3(sa, sb, sr, smem);
+  if (threadIdx.x == 0) {
+    double* p = partial + (b * gridDim.x + blockIdx.x) * 3;
+    p[0] = sa;
+    p[1] = sb;
+    p[2] = sr;
+  }
+}
+
 // The scalar tail of Add.relprop: a_fact / b_fact and the two rescale factors, in fp32 like the
 // reference's 0-d tensors (layers_ours.py:112-116).
 __device__ __forceinline__ void add_factors(double A, double Bs, double Rs, float& fa, float& fb) {
@@ -71,6 +127,35 @@ __device__ __forceinline__ void add_factors(double A, double Bs, double Rs, floa
   const float b_fact = te_sd(b_abs, den) * r_sum;
   fa = te_sd(a_fact, a_sum);
   fb = te_sd(b_fact, b_sum);
+}
+
+// One wave folds the chunk partials of sample b in a fixed tree (the order every user of the partials shares).
+__device__ __forceinline__ void fold_partials(const double* __restrict__ partial, int64_t b, int nb, double& sa,
+                                              double& sb, double& sr) {
+  sa = sb = sr = 0.0;
+  for (int p = threadIdx.x; p < nb; p += 64) {
+    const double* q = partial + (b * nb + p) * 3;
+    sa += q[0];
+    sb += q[1];
+    sr += q[2];
+  }
+  sa = te_wave_sum(sa);
+  sb = te_wave_sum(sb);
+  sr = te_wave_sum(sr);
+}
+
+// fac[b] = {fa, fb} from the chunk partials: one wave per sample
+__global__ __launch_bounds__(64) void add_factors_kernel(const double* __restrict__ partial, float* __restrict__ fac,
+                                                         int nb) {
+  const int64_t b = blockIdx.x;
+  double sa, sb, sr;
+  fold_partials(partial, b, nb, sa, sb, sr);
+  if (threadIdx.x == 0) {
+    float fa, fb;
+    add_factors(sa, sb, sr, fa, fb);
+    fac[2 * b] = fa;
+    fac[2 * b + 1] = fb;
+  }
 }
 
 // Pass 2 (ours) / the only pass (lrp): recompute a, b and apply the per-sample factors.
@@ -84,17 +169,8 @@ __global__ __launch_bounds__(kThreads) void add_apply_kernel(
   float fa = 1.0f, fb = 1.0f;
   if constexpr (OURS) {
     if (threadIdx.x < 64) {  // one wave folds the chunk partials of this sample in a fixed tree
-      const int nb = gridDim.x;
-      double sa = 0.0, sb = 0.0, sr = 0.0;
-      for (int p = threadIdx.x; p < nb; p += 64) {
-        const double* q = partial + (b * nb + p) * 3;
-        sa += q[0];
-        sb += q[1];
-        sr += q[2];
-      }
-      sa = te_wave_sum(sa);
-      sb = te_wave_sum(sb);
-      sr = te_wave_sum(sr);
+      double sa, sb, sr;
+      fold_partials(partial, b, gridDim.x, sa, sb, sr);
       if (threadIdx.x == 0) {
         add_factors(sa, sb, sr, fa, fb);
         fac[0] = fa;
@@ -287,6 +363,45 @@ __global__ __launch_bounds__(kThreads) void clone_kernel(
   }
 }
 
+// Clone.relprop whose relevance operands carry a deferred per-sample factor (the unscaled outputs of
+// te_add_relprop_deferred_f32): R_i enters as R_i[e] * s_i[sample]; s_i == NULL means 1.  2-D grid (chunks, samples).
+template <int VEC, int NUM>
+__global__ __launch_bounds__(kThreads) void clone_scaled_kernel(
+    const float* __restrict__ R0, const float* __restrict__ s0, int64_t s0_stride, const float* __restrict__ R1,
+    const float* __restrict__ s1, int64_t s1_stride, const float* __restrict__ R2, const float* __restrict__ s2,
+    int64_t s2_stride, const float* __restrict__ X, float* __restrict__ out, int64_t n) {
+  const int64_t b = blockIdx.y;
+  const float f0 = s0 ? s0[b * s0_stride] : 1.0f, f1 = s1 ? s1[b * s1_stride] : 1.0f;
+  const float f2 = (NUM == 3 && s2) ? s2[b * s2_stride] : 1.0f;
+  const float* r0 = R0 + b * n;
+  const float* r1 = R1 + b * n;
+  const float* r2 = (NUM == 3) ? R2 + b * n : nullptr;
+  const float* x_ = X + b * n;
+  float* o = out + b * n;
+  const int64_t stride = (int64_t)gridDim.x * kThreads * VEC;
+  for (int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * VEC; i < n; i += stride) {
+    if constexpr (VEC == 4) {
+      const f32x4 x = ld<f32x4>(x_ + i), a = ld<f32x4>(r0 + i), bq = ld<f32x4>(r1 + i);
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (NUM == 3) c = ld<f32x4>(r2 + i);
+      f32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ra = s0 ? a[e] * f0 : a[e], rb = s1 ? bq[e] * f1 : bq[e];
+        float s = te_sd(ra, x[e]) + te_sd(rb, x[e]);
+        if constexpr (NUM == 3) s = s + te_sd(s2 ? c[e] * f2 : c[e], x[e]);
+        ov[e] = x[e] * s;
+      }
+      st<f32x4>(o + i, ov);
+    } else {
+      const float x = x_[i];
+      float s = te_sd(s0 ? r0[i] * f0 : r0[i], x) + te_sd(s1 ? r1[i] * f1 : r1[i], x);
+      if constexpr (NUM == 3) s = s + te_sd(s2 ? r2[i] * f2 : r2[i], x);
+      o[i] = x * s;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // IndexSelect.relprop (modules/layers_ours.py:129-147), dim = 1, single index.
 // ------------------------------------------------------------------------------------------------
@@ -360,6 +475,47 @@ __global__ __launch_bounds__(kThreads) void headmean_kernel(
   }
 }
 
+// All heads' loads of a thread in flight at once (2 H independent 16-B loads, H <= HMAX), one float4 per thread, grid =
+// (ceil(NN / 1024), B): every block does the same amount of work and the dispatcher back-fills finished blocks
+// (the grid-stride form above gives 6 of 32 blocks per sample a second trip at N = 197).  Heads are still added in
+// index order.
+template <int HMAX>
+__global__ __launch_bounds__(kThreads) void headmean_flat_kernel(
+    const float* __restrict__ grad, const float* __restrict__ cam, float* __restrict__ out, int H, int64_t NN) {
+  const int64_t b = blockIdx.y;
+  const float fH = (float)H;
+  const float* g = grad + b * H * NN;
+  const float* c = cam + b * H * NN;
+  float* o = out + b * NN;
+  const int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (e >= NN) return;
+  if (e + 3 < NN) {
+    f32x4_u gv[HMAX], cv[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+        gv[h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_u*>(g + h * NN + e));
+        cv[h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_u*>(c + h * NN + e));
+      }
+    f32x4_u acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = acc[k] + fmaxf(gv[h][k] * cv[h][k], 0.0f);
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = acc[k] / fH;
+    st<f32x4_u>(o + e, acc);
+  } else {
+    for (int64_t ee = e; ee < NN; ++ee) {
+      float acc = 0.0f;
+      for (int h = 0; h < H; ++h) acc = acc + fmaxf(g[h * NN + ee] * c[h * NN + ee], 0.0f);
+      o[ee] = acc / fH;
+    }
+  }
+}
+
 inline int pick_blocks_per_sample(int64_t B, int64_t n) {
   // >= ~2048 blocks in flight for the chip (256 CUs x 8), each block >= 4096 elements, <= 64 chunks.
   int64_t bps = te_ceil_div(2048, B);
@@ -412,6 +568,33 @@ extern "C" int te_add_relprop_f32(const float* R, const float* X0, const float* 
       add_apply_kernel<1, false><<<grid, block, 0, stream>>>(R, X0, X1, out0, out1, nullptr, n,
                                                              x1_batch_stride, chunk);
   }
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// ---- Add with the per-sample rescale deferred to the consumers ---------------------------------------
+extern "C" size_t te_add_relprop_deferred_workspace_bytes(int64_t B, int64_t n) {
+  return te_add_relprop_workspace_bytes(B, n);
+}
+
+extern "C" int te_add_relprop_deferred_f32(const float* R, const float* X0, const float* X1, float* a, float* b,
+                                           float* fac, int64_t B, int64_t n, int64_t x1_batch_stride, void* ws,
+                                           size_t ws_bytes, te_stream_t stream_) {
+  if (!R || !X0 || !X1 || !a || !b || !fac || B <= 0 || n <= 0) return TE_ERR_INVALID_ARG;
+  if (x1_batch_stride != 0 && x1_batch_stride != n) return TE_ERR_INVALID_ARG;
+  if (B > 65535) return TE_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < te_add_relprop_workspace_bytes(B, n)) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool vec = (n % 4 == 0) && te_aligned16(R) && te_aligned16(X0) && te_aligned16(X1) && te_aligned16(a) &&
+                   te_aligned16(b);
+  const int bps = pick_blocks_per_sample(B, n);      // the same chunking (and fold order) as te_add_relprop_f32
+  int64_t chunk = te_ceil_div(n, bps);
+  chunk = te_ceil_div(chunk, 4) * 4;
+  dim3 grid(bps, (unsigned)B), block(kThreads);
+  double* partial = (double*)ws;
+  if (vec) add_deferred_kernel<4><<<grid, block, 0, stream>>>(R, X0, X1, a, b, partial, n, x1_batch_stride, chunk);
+  else add_deferred_kernel<1><<<grid, block, 0, stream>>>(R, X0, X1, a, b, partial, n, x1_batch_stride, chunk);
+  add_factors_kernel<<<dim3((unsigned)B), dim3(64), 0, stream>>>(partial, fac, bps);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
@@ -485,6 +668,35 @@ extern "C" int te_clone_relprop_f32(const float* R0, const float* R1, const floa
   return TE_OK;
 }
 
+extern "C" int te_clone_relprop_scaled_f32(const float* R0, const float* s0, int64_t s0_stride, const float* R1,
+                                           const float* s1, int64_t s1_stride, const float* R2, const float* s2,
+                                           int64_t s2_stride, const float* X, float* out, int64_t B, int64_t n,
+                                           te_stream_t stream_) {
+  if (!R0 || !R1 || !X || !out || B <= 0 || n <= 0) return TE_ERR_INVALID_ARG;
+  if (B > 65535) return TE_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool vec = (n % 4 == 0) && te_aligned16(R0) && te_aligned16(R1) && te_aligned16(X) && te_aligned16(out) &&
+                   (!R2 || te_aligned16(R2));
+  const int vecw = vec ? 4 : 1;
+  int64_t bx = te_ceil_div(n, (int64_t)kThreads * vecw * 2);
+  const int64_t want = te_ceil_div(4096, B);
+  if (bx > want) bx = want;
+  if (bx < 1) bx = 1;
+  dim3 grid((unsigned)bx, (unsigned)B), block(kThreads);
+#define TE_CLONE_S(V, NUM) \
+  clone_scaled_kernel<V, NUM><<<grid, block, 0, stream>>>(R0, s0, s0_stride, R1, s1, s1_stride, R2, s2, s2_stride, X, out, n)
+  if (R2) {
+    if (vec) TE_CLONE_S(4, 3);
+    else TE_CLONE_S(1, 3);
+  } else {
+    if (vec) TE_CLONE_S(4, 2);
+    else TE_CLONE_S(1, 2);
+  }
+#undef TE_CLONE_S
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
 // ---- IndexSelect ------------------------------------------------------------------------------------
 extern "C" int te_index_select_relprop_f32(const float* R, const float* X, float* out, int64_t B,
                                            int64_t N, int64_t C, int64_t index, te_stream_t stream_) {
@@ -505,6 +717,18 @@ extern "C" int te_gradcam_headmean_f32(const float* grad, const float* cam, floa
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t NN = N * N;
   int64_t bx = te_ceil_div(NN, (int64_t)kThreads * 4);
+  // TE_HEADMEAN_VARIANT (tuning): 0 = grid-stride kernel (<= 2048 blocks), 1 = flat kernel, every head in flight (default)
+  static const int variant = [] {
+    const char* e = getenv("TE_HEADMEAN_VARIANT");
+    return e ? atoi(e) : 1;
+  }();
+  if (variant == 1 && H <= 16 && B <= 65535) {
+    const dim3 grid((unsigned)bx, (unsigned)B), blk(kThreads);
+    if (H <= 12) headmean_flat_kernel<12><<<grid, blk, 0, stream>>>(grad, cam, out, (int)H, NN);
+    else headmean_flat_kernel<16><<<grid, blk, 0, stream>>>(grad, cam, out, (int)H, NN);
+    TE_RETURN_IF_LAUNCH_FAILED();
+    return TE_OK;
+  }
   const int64_t want = te_ceil_div(2048, B);
   if (bx > want) bx = want;
   if (bx < 1) bx = 1;

@@ -198,11 +198,37 @@ __device__ __noinline__ float exact_z(const float* __restrict__ x, const float* 
   return z1 + z2;
 }
 
+// Deferred per-sample factor on the relevance operand (te_add_relprop_deferred_f32 hands out b = X1.S unscaled plus
+// fac[sample]): row t of R enters the rule as R[t,:] * s[(t / rps) * stride] -- the product the Add's apply pass would
+// have stored.  s == NULL: no factor.
+struct RowScale {
+  const float* s;
+  int64_t stride;
+  int rps;          // rows per sample
+};
+// factors of the (up to 32) rows gr0 + crow(e) of one 32x32 accumulator block
+__device__ __forceinline__ void row_factors(const RowScale& rs, int64_t gr0, int64_t T, float (&f)[16]) {
+  if (rs.rps >= 40) {      // a 36-row span (4*kh + crow < 36) touches at most two samples
+    const int64_t b0 = gr0 / rs.rps, edge = (b0 + 1) * rs.rps;
+    const float f0 = rs.s[b0 * rs.stride];
+    const float f1 = (edge < T) ? rs.s[(b0 + 1) * rs.stride] : f0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) f[e] = (gr0 + (e & 3) + 8 * (e >> 2) < edge) ? f0 : f1;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t gr = min(gr0 + (e & 3) + 8 * (e >> 2), T - 1);
+      f[e] = rs.s[(gr / rs.rps) * rs.stride];
+    }
+  }
+}
+
 template <int ZM, bool SWAP, int BM, int BN, int VAR = 0>
 __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ R,
     const float* __restrict__ Y, const float* __restrict__ bias,
-    float* __restrict__ S1, float* __restrict__ S2, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles) {
+    float* __restrict__ S1, float* __restrict__ S2, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles,
+    RowScale rs) {
   constexpr bool LRP = (ZM == ZM_LRP), FWD = (ZM == ZM_FWD);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MI = BM / 64, NI = BN / 64;   // 32x32 MFMA blocks per wave
@@ -445,6 +471,12 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
             yy[e] = Y[at];
           }
           const float bb = bias ? bias[gc] : 0.0f;
+          if (rs.s) {
+            float fr[16];
+            row_factors(rs, gr0, T, fr);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rr[e] = rr[e] * fr[e];
+          }
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t gr = gr0 + (e & 3) + 8 * (e >> 2);
@@ -466,7 +498,8 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
       for (int e = 0; e < 16; ++e) {
         const int64_t gr = tc.row0 + wm * WM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         if (gr < T && gc < Nn) {
-          const float r = R[gr * Nn + gc];
+          float r = R[gr * Nn + gc];
+          if (rs.s) r = r * rs.s[(gr / rs.rps) * rs.stride];
           if constexpr (LRP) {
             S1[gr * Nn + gc] = te_sd(r, acc[0][mi][ni][e]);
             S2[gr * Nn + gc] = te_sd(r, acc[1][mi][ni][e]);
@@ -755,17 +788,18 @@ inline Tile pick_tile(int64_t T, int64_t n_out, bool one_product = false) {
 
 template <int ZM, bool SWAP, int BM, int BN, int VAR = 0>
 inline void launch_k1v(const float* X, const float* W, const float* R, const float* Y, const float* bias, float* S1,
-                       float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream) {
+                       float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream, RowScale rs) {
   const int nbn = (int)te_ceil_div(out_f, BN);
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k1_lds<BM, BN>();
   allow_lds(linear_k1_kernel<ZM, SWAP, BM, BN, VAR>, lds);
   linear_k1_kernel<ZM, SWAP, BM, BN, VAR><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
-      X, W, R, Y, bias, S1, S2, T, in_f, out_f, nbn, ntiles);
+      X, W, R, Y, bias, S1, S2, T, in_f, out_f, nbn, ntiles, rs);
 }
 template <int ZM, bool SWAP, int BM, int BN>
 inline void launch_k1(const float* X, const float* W, const float* R, const float* Y, const float* bias, float* S1,
-                      float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream) {
+                      float* S2, int64_t T, int64_t in_f, int64_t out_f, hipStream_t stream,
+                      RowScale rs = RowScale{nullptr, 0, 1}) {
   if constexpr (ZM == ZM_FWD) {
     // TE_ZFWD_VARIANT (tuning study, profiles/r01_zfwd_variants.log): 0 = per-element epilogue, distance-1 prefetch;
     // 1 = batched epilogue loads (-3.5 %); 2 = 1 + prefetch distance 2 (-6.3 %, default)
@@ -774,12 +808,12 @@ inline void launch_k1(const float* X, const float* W, const float* R, const floa
       return e ? atoi(e) : 2;
     }();
     switch (var) {
-      case 0: return launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
-      case 1: return launch_k1v<ZM, SWAP, BM, BN, 1>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
-      default: return launch_k1v<ZM, SWAP, BM, BN, 2>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
+      case 0: return launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
+      case 1: return launch_k1v<ZM, SWAP, BM, BN, 1>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
+      default: return launch_k1v<ZM, SWAP, BM, BN, 2>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
     }
   }
-  launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream);
+  launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
 }
 template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
 inline void launch_k2(const float* S, const float* W, const float* X, float* out, int64_t T, int64_t in_f,
@@ -881,31 +915,48 @@ extern "C" int te_linear_cpass_f32(const float* S, const float* X, const float* 
 }
 
 // ---- Z-pass from the forward output (see K1f in the file header), alone and composed with the C-pass
-extern "C" int te_linear_zpass_fwd_f32(const float* R, const float* X, const float* W, const float* Y,
-                                       const float* bias, float* S, int64_t T, int64_t in_f, int64_t out_f,
-                                       te_stream_t stream_) {
+extern "C" int te_linear_zpass_fwd_scaled_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
+                                              int64_t rows_per_sample, const float* X, const float* W, const float* Y,
+                                              const float* bias, float* S, int64_t T, int64_t in_f, int64_t out_f,
+                                              te_stream_t stream_) {
   if (!R || !X || !W || !Y || !S || T <= 0 || in_f <= 0 || out_f <= 0) return TE_ERR_INVALID_ARG;
+  if (r_scale && (rows_per_sample <= 0 || rows_per_sample > 0x7fffffff || T % rows_per_sample)) return TE_ERR_INVALID_ARG;
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(R) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(S))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
-#define TE_K1(BM_, BN_) launch_k1<ZM_FWD, false, BM_, BN_>(X, W, R, Y, bias, S, S, T, in_f, out_f, stream)
+  const RowScale rs{r_scale, r_scale_stride, r_scale ? (int)rows_per_sample : 1};
+#define TE_K1(BM_, BN_) launch_k1<ZM_FWD, false, BM_, BN_>(X, W, R, Y, bias, S, S, T, in_f, out_f, stream, rs)
   TE_DISPATCH_TILE(pick_tile(T, out_f, true), TE_K1);
 #undef TE_K1
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
 
-extern "C" int te_linear_relprop_fwd_f32(const float* R, const float* X, const float* W, const float* Y,
-                                         const float* bias, float* out, int64_t T, int64_t in_f, int64_t out_f,
-                                         void* ws, size_t ws_bytes, te_stream_t stream_) {
+extern "C" int te_linear_zpass_fwd_f32(const float* R, const float* X, const float* W, const float* Y,
+                                       const float* bias, float* S, int64_t T, int64_t in_f, int64_t out_f,
+                                       te_stream_t stream_) {
+  return te_linear_zpass_fwd_scaled_f32(R, nullptr, 0, 1, X, W, Y, bias, S, T, in_f, out_f, stream_);
+}
+
+extern "C" int te_linear_relprop_fwd_scaled_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
+                                                int64_t rows_per_sample, const float* X, const float* W,
+                                                const float* Y, const float* bias, float* out, int64_t T, int64_t in_f,
+                                                int64_t out_f, void* ws, size_t ws_bytes, te_stream_t stream_) {
   if (!R || !X || !W || !Y || !out || T <= 0 || in_f <= 0 || out_f <= 0) return TE_ERR_INVALID_ARG;
   if (!ws || ws_bytes < te_linear_relprop_workspace_bytes(T, in_f, out_f, TE_VARIANT_OURS)) return TE_ERR_WORKSPACE;
   if (!te_aligned16(ws)) return TE_ERR_WORKSPACE;
   if ((in_f % 4) || (out_f % 4) || !te_aligned16(R) || !te_aligned16(X) || !te_aligned16(W) || !te_aligned16(out))
     return TE_ERR_UNSUPPORTED;   // callers fall back to te_linear_relprop_f32 (any shape)
-  int rc = te_linear_zpass_fwd_f32(R, X, W, Y, bias, (float*)ws, T, in_f, out_f, stream_);
+  int rc = te_linear_zpass_fwd_scaled_f32(R, r_scale, r_scale_stride, rows_per_sample, X, W, Y, bias, (float*)ws, T,
+                                          in_f, out_f, stream_);
   if (rc != TE_OK) return rc;
   return te_linear_cpass_f32((const float*)ws, X, W, out, T, in_f, out_f, stream_);
+}
+
+extern "C" int te_linear_relprop_fwd_f32(const float* R, const float* X, const float* W, const float* Y,
+                                         const float* bias, float* out, int64_t T, int64_t in_f, int64_t out_f,
+                                         void* ws, size_t ws_bytes, te_stream_t stream_) {
+  return te_linear_relprop_fwd_scaled_f32(R, nullptr, 0, 1, X, W, Y, bias, out, T, in_f, out_f, ws, ws_bytes, stream_);
 }
 
 extern "C" size_t te_linear_relprop_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f, int variant) {

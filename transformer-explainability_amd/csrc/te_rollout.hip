@@ -9,6 +9,16 @@
 // (rollout_bmm_mfma_kernel in te_attn_mfma.hip, the tile machinery of the attention rules).  The plain kernel below
 // (LDS-staged 16-deep K slices, 4 x 4 register micro-tile per thread, k-ordered fmaf chains) is its cross-check,
 // selected by TE_IMPL_SIMPLE in `flags`.
+//
+// TE_ROLLOUT_ROW0: both generators read ROW 0 of the joint matrix only (ViT_LRP.py:369 `[:, 0, 1:]`,
+// ExplanationGenerator.py:58-59 `rollout[:, 0]`), and row 0 of M_{L-1} ... M_s is the vector chain
+//   r = e_0^T M_{L-1} ;  r = r M_i  (i = L-2 .. s)
+// -- (L - s) vector x matrix steps that read every layer's N x N matrix once (HBM-bound, (L-s) N^2 4 B per sample)
+// instead of (L-1-s) full N^3 products.  rollout_row_step_kernel: one block per (sample, 16-row slab of M_i); each
+// wave takes rows k of the slab, builds (A[k,:] + e_k) [/ rowsum] on the fly from the head-mean matrix (no M copy),
+// and accumulates r[k] * row into per-lane registers; the four waves are folded through LDS in a fixed order and
+// the slab's partial vector goes to the workspace, which the NEXT step folds (again in slab order) into its r.
+// Slab size and fold order depend on N only, so a batch equals its samples run one by one, bit for bit.
 #include "te_common.h"
 
 namespace te_attn_mfma {
@@ -115,6 +125,106 @@ __global__ __launch_bounds__(64) void rollout_cls_fixup_kernel(float* __restrict
   if (threadIdx.x == 0) row[0] = m;
 }
 
+
+// ---- row-0 chain ------------------------------------------------------------------------------------------------
+constexpr int kRowSlab = 16;      // rows of M_i per block
+constexpr int kRowMaxJ = 16;      // columns per lane: N <= 64 * 16 = 1024
+
+// partial_out[b, slab, :] = sum_{k in slab} r[k] * M[k, :],  M = (A + I) [/ rowsum(A + I)]
+//   r[k] = sum over the previous step's slabs of partial_in[b, slab', k]  (fixed order), or e_0 when FIRST
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads) void rollout_row_step_kernel(
+    const float* __restrict__ A, const float* __restrict__ partial_in, float* __restrict__ partial_out, int N,
+    int nslab_in, int normalise) {
+  __shared__ float r_s[kRowSlab];
+  __shared__ float fold[kThreads / 64 - 1][64 * kRowMaxJ];
+  const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k0 = slab * kRowSlab, k1 = min(N, k0 + kRowSlab);
+  if (threadIdx.x < kRowSlab) {
+    const int k = k0 + threadIdx.x;
+    float r = 0.0f;
+    if (k < N) {
+      if constexpr (FIRST) {
+        r = (k == 0) ? 1.0f : 0.0f;
+      } else {
+        const float* p = partial_in + (int64_t)b * nslab_in * N + k;
+        for (int s = 0; s < nslab_in; ++s) r = r + p[(int64_t)s * N];
+      }
+    }
+    r_s[threadIdx.x] = r;
+  }
+  __syncthreads();
+  float acc[kRowMaxJ];
+#pragma unroll
+  for (int m = 0; m < kRowMaxJ; ++m) acc[m] = 0.0f;
+  const float* a_b = A + (int64_t)b * N * N;
+  const int kend = FIRST ? min(k1, 1) : k1;      // e_0^T M needs row 0 only
+  for (int k = k0 + wave; k < kend; k += kThreads / 64) {
+    const float rk = r_s[k - k0];
+    const float* row = a_b + (int64_t)k * N;
+    float v[kRowMaxJ];
+#pragma unroll
+    for (int m = 0; m < kRowMaxJ; ++m) {
+      const int j = lane + 64 * m;
+      v[m] = (j < N) ? (row[j] + (j == k ? 1.0f : 0.0f)) : 0.0f;
+    }
+    if (normalise) {
+      double s = 0.0;
+#pragma unroll
+      for (int m = 0; m < kRowMaxJ; ++m)
+        if (lane + 64 * m < N) s += (double)v[m];
+      s = te_wave_sum(s);
+      const float den = (float)__shfl(s, 0, 64);
+#pragma unroll
+      for (int m = 0; m < kRowMaxJ; ++m) v[m] = v[m] / den;
+    }
+#pragma unroll
+    for (int m = 0; m < kRowMaxJ; ++m) acc[m] = fmaf(rk, v[m], acc[m]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int m = 0; m < kRowMaxJ; ++m) fold[wave - 1][m * 64 + lane] = acc[m];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = partial_out + ((int64_t)b * nslab + slab) * N;
+#pragma unroll
+    for (int m = 0; m < kRowMaxJ; ++m) {
+      const int j = lane + 64 * m;
+      float t = acc[m];
+#pragma unroll
+      for (int w = 0; w < kThreads / 64 - 1; ++w) t = t + fold[w][m * 64 + lane];
+      if (j < N) out[j] = t;
+    }
+  }
+}
+
+// joint_row[b, :] = sum over slabs of partial[b, slab, :]; optional CLS fix-up joint_row[b,0] = min_j joint_row[b,j]
+__global__ __launch_bounds__(kThreads) void rollout_row_finish_kernel(const float* __restrict__ partial,
+                                                                      float* __restrict__ out, int N, int nslab,
+                                                                      int cls_fixup) {
+  __shared__ float red[kThreads / 64];
+  const int b = blockIdx.x;
+  const float* p = partial + (int64_t)b * nslab * N;
+  float mn = INFINITY;
+  for (int j = threadIdx.x; j < N; j += kThreads) {
+    float r = 0.0f;
+    for (int s = 0; s < nslab; ++s) r = r + p[(int64_t)s * N + j];
+    out[(int64_t)b * N + j] = r;
+    mn = fminf(mn, r);
+  }
+  if (!cls_fixup) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_down(mn, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = red[0];
+    for (int w = 1; w < kThreads / 64; ++w) m = fminf(m, red[w]);
+    out[(int64_t)b * N] = m;
+  }
+}
 }  // namespace
 
 // workspace: M [L,B,N,N] (identity added / normalised copies) + one ping-pong joint [B,N,N]
@@ -125,13 +235,40 @@ extern "C" size_t te_rollout_workspace_bytes(int64_t L, int64_t B, int64_t N) {
   return m + j;
 }
 
+// row-0 chain: two ping-pong slab-partial buffers [B, ceil(N/16), N]
+extern "C" size_t te_rollout_row0_workspace_bytes(int64_t B, int64_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  return 2 * te_align_up((size_t)B * te_ceil_div(N, kRowSlab) * N * sizeof(float), 256);
+}
+
 extern "C" int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
                               int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream_) {
   if (!cams || !joint || L <= 0 || B <= 0 || N <= 0 || start_layer < 0 || start_layer >= L)
     return TE_ERR_INVALID_ARG;
-  if (!ws || ws_bytes < te_rollout_workspace_bytes(L, B, N)) return TE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t mat = B * N * N;
+  if (flags & TE_ROLLOUT_ROW0) {
+    // joint is [B,N]: row 0 of the chain product only
+    if (N > 64 * kRowMaxJ || B > 65535) return TE_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < te_rollout_row0_workspace_bytes(B, N)) return TE_ERR_WORKSPACE;
+    const int nslab = (int)te_ceil_div(N, kRowSlab);
+    float* pp[2] = {(float*)ws, (float*)((char*)ws + te_align_up((size_t)B * nslab * N * sizeof(float), 256))};
+    const int norm = (flags & TE_ROLLOUT_NORMALISE) ? 1 : 0;
+    const dim3 grid((unsigned)nslab, (unsigned)B), blk(kThreads);
+    int cur = 0;
+    // e_0^T M_{L-1}: only slab 0 has a non-zero row, the others write zeros (uniform fold in the next step)
+    rollout_row_step_kernel<true><<<grid, blk, 0, stream>>>(cams + (L - 1) * mat, nullptr, pp[cur], (int)N, 0, norm);
+    for (int64_t i = L - 2; i >= start_layer; --i) {
+      rollout_row_step_kernel<false><<<grid, blk, 0, stream>>>(cams + i * mat, pp[cur], pp[cur ^ 1], (int)N, nslab,
+                                                               norm);
+      cur ^= 1;
+    }
+    rollout_row_finish_kernel<<<dim3((unsigned)B), blk, 0, stream>>>(pp[cur], joint, (int)N, nslab,
+                                                                    (flags & TE_ROLLOUT_CLS_FIXUP) ? 1 : 0);
+    TE_RETURN_IF_LAUNCH_FAILED();
+    return TE_OK;
+  }
+  if (!ws || ws_bytes < te_rollout_workspace_bytes(L, B, N)) return TE_ERR_WORKSPACE;
   float* M = (float*)ws;
   float* tmp = (float*)((char*)ws + te_align_up((size_t)L * mat * sizeof(float), 256));
   // only layers start..L-1 are consumed

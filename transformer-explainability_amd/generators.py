@@ -96,14 +96,21 @@ class LRP:
         one_hot = _one_hot(output, index)
         loss = torch.sum(one_hot * output)
         prune = self.prune and method in ("transformer_attribution", "grad")
-        self.model.prune_below_start_layer = prune
-        self._grad_blocks = list(self.model.blocks)[start_layer if prune else 0:]
-        if self.overlap_backward and input.is_cuda:
-            return self._relprop_beside_backward(loss, one_hot, method, is_ablation, start_layer, kwargs)
-        _attention_gradients(loss, [blk.attn for blk in self._grad_blocks])
-        return self.model.relprop(one_hot, method=method, is_ablation=is_ablation, start_layer=start_layer, **kwargs)
+        # the flag is set for THIS call only: a user's own setting of model.prune_below_start_layer (and direct
+        # model.relprop calls afterwards) are unaffected
+        user_flag = self.model.prune_below_start_layer
+        self.model.prune_below_start_layer = prune or (user_flag and method in ("transformer_attribution", "grad"))
+        grad_blocks = list(self.model.blocks)[start_layer if self.model.prune_below_start_layer else 0:]
+        try:
+            if self.overlap_backward and input.is_cuda:
+                return self._relprop_beside_backward(loss, one_hot, method, is_ablation, start_layer, kwargs, grad_blocks)
+            _attention_gradients(loss, [blk.attn for blk in grad_blocks])
+            return self.model.relprop(one_hot, method=method, is_ablation=is_ablation, start_layer=start_layer,
+                                      **kwargs)
+        finally:
+            self.model.prune_below_start_layer = user_flag
 
-    def _relprop_beside_backward(self, loss, one_hot, method, is_ablation, start_layer, kwargs):
+    def _relprop_beside_backward(self, loss, one_hot, method, is_ablation, start_layer, kwargs, grad_blocks):
         dev = one_hot.device
         main = torch.cuda.current_stream(dev)
         if self._relprop_stream is None:
@@ -111,7 +118,7 @@ class LRP:
         side = self._relprop_stream
         side.wait_stream(main)                      # forward caches + one-hot are complete
         # backward on the main stream (autograd runs each node on its forward op's stream)
-        _attention_gradients(loss, [blk.attn for blk in self._grad_blocks])
+        _attention_gradients(loss, [blk.attn for blk in grad_blocks])
         grads_ready = main.record_event()
         self.model._before_tail = lambda: torch.cuda.current_stream(dev).wait_event(grads_ready)
         try:
@@ -284,8 +291,7 @@ class Generator:
             if i >= start_layer or not self.prune:            # (the rollout reads layers >= start_layer only)
                 ops.gradcam_headmean(sa.get_attn_gradients(), sa.get_attn_cam(), out=stack[i])
         # ExplanationGenerator.py:7-18 (row-normalised rollout) + :58 (CLS fix-up) -> row 0
-        joint = ops.rollout(stack, start_layer=start_layer, normalise=True, cls_fixup=True)
-        return joint[:, 0]
+        return ops.rollout(stack, start_layer=start_layer, normalise=True, cls_fixup=True, row0_only=True)
 
     def generate_LRP_last_layer(self, input_ids, attention_mask, index=None):
         """ExplanationGenerator.py:62-84: head-mean of the last layer's attn_cam, CLS row, CLS slot zeroed."""

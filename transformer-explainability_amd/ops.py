@@ -6,20 +6,49 @@ relprop rules; see include/te_relprop.h for the exact semantics and reference ci
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib
-from ._lib import TE_IMPL_SIMPLE, TE_ROLLOUT_CLS_FIXUP, TE_ROLLOUT_NORMALISE, TE_VARIANT_LRP, TE_VARIANT_OURS
+from ._lib import (TE_IMPL_SIMPLE, TE_ROLLOUT_CLS_FIXUP, TE_ROLLOUT_NORMALISE, TE_ROLLOUT_ROW0, TE_VARIANT_LRP,
+                   TE_VARIANT_OURS)
 
 Tensor = torch.Tensor
 _VARIANTS = {"ours": TE_VARIANT_OURS, "lrp": TE_VARIANT_LRP}
 
 # Tests flip this to run the simple (non-MFMA) device kernels as an on-device cross-check.
 FORCE_SIMPLE = False
-# bench.py installs a callable (name, flops) -> context manager here to time single kernel launches.
+# bench.py installs a callable (name, flops, bytes) -> context manager here: every C-ABI call of the relprop path is
+# then bracketed by HIP events on the stream it launches on, tagged with its ALGORITHMIC work.
 KERNEL_TIMER = None
+_NULL = contextlib.nullcontext()
+
+
+def _timed(name: str, flops: float = 0.0, nbytes: float = 0.0):
+    return _NULL if KERNEL_TIMER is None else KERNEL_TIMER(name, float(flops), float(nbytes))
+
+
+class Deferred:
+    """A relevance tensor whose per-sample factor has not been applied yet: value = t * scale[b] with scale a strided
+    view into the [B,2] factor pair of te_add_relprop_deferred_f32.  Consumers (clone_relprop, linear_relprop) take the
+    factor into their kernels; ``materialise()`` gives the plain tensor (bitwise what Add.relprop returns)."""
+    __slots__ = ("t", "scale")
+
+    def __init__(self, t: Tensor, scale: Tensor):
+        self.t, self.scale = t, scale
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def materialise(self) -> Tensor:
+        return self.t * self.scale.view(-1, *([1] * (self.t.dim() - 1)))
+
+
+def _split_deferred(x):
+    return (x.t, x.scale) if isinstance(x, Deferred) else (x, None)
 _checked_device = False
 
 
@@ -88,14 +117,22 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
     (variant ours, alpha = 1) the Z-pass needs one product instead of two."""
     out_f, in_f = W.shape
     lead = X.shape[:-1]
+    R, r_scale = _split_deferred(R)
     Rc, Xc, Wc = _c(R).reshape(-1, out_f), _c(X).reshape(-1, in_f), _c(W)
     T = Xc.shape[0]
     if Rc.shape[0] != T:
         raise _lib.TeError(f"Linear.relprop: R has {Rc.shape[0]} rows, X has {T}")
     out = torch.empty((T, in_f), dtype=torch.float32, device=X.device)
     var = _variant(variant)
-    fast_ok = var == TE_VARIANT_OURS and alpha == 1 and in_f % 4 == 0 and out_f % 4 == 0
+    fast_ok = (var == TE_VARIANT_OURS and alpha == 1 and in_f % 4 == 0 and out_f % 4 == 0 and
+               all(t.data_ptr() % 16 == 0 for t in (Rc, Xc, Wc)))      # (else: the any-shape entry point)
     fwd = fast_ok and USE_FORWARD_OUTPUT and Y is not None
+    if r_scale is not None and not fwd:      # only the forward-output Z-pass takes the factor into its epilogue
+        Rc = _c(Deferred(R, r_scale).materialise()).reshape(-1, out_f)
+        r_scale = None
+    rs_ptr, rs_stride, rps = None, 0, 1
+    if r_scale is not None:
+        rs_ptr, rs_stride, rps = r_scale.data_ptr(), r_scale.stride(0), T // r_scale.shape[0]
     if fwd:
         Yc = _c(Y.detach()).reshape(-1, out_f)
         bc = None if bias is None else _c(bias.detach())
@@ -108,23 +145,25 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
             S = torch.empty((T, out_f), dtype=torch.float32, device=X.device)
             st = _stream(Xc)
             if fwd:
-                with KERNEL_TIMER("linear_zpass_fwd", 2.0 * T * in_f * out_f):
-                    _lib.check(lib.te_linear_zpass_fwd_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(Yc), _ptr(bc), _ptr(S), T,
-                                                           in_f, out_f, st), "te_linear_zpass_fwd_f32")
+                with _timed("linear_zpass_fwd", 2.0 * T * in_f * out_f, 4.0 * (T * in_f + 3 * T * out_f + in_f * out_f)):
+                    _lib.check(lib.te_linear_zpass_fwd_scaled_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc),
+                                                                  _ptr(Yc), _ptr(bc), _ptr(S), T, in_f, out_f, st),
+                               "te_linear_zpass_fwd_scaled_f32")
             else:
-                with KERNEL_TIMER("linear_zpass", 2.0 * T * (2 * in_f) * out_f):
+                with _timed("linear_zpass", 2.0 * T * (2 * in_f) * out_f, 4.0 * (T * in_f + 2 * T * out_f + in_f * out_f)):
                     _lib.check(lib.te_linear_zpass_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(S), T, in_f, out_f, st),
                                "te_linear_zpass_f32")
-            with KERNEL_TIMER("linear_cpass", 2.0 * T * (2 * in_f) * out_f):
+            with _timed("linear_cpass", 2.0 * T * (2 * in_f) * out_f, 4.0 * (T * out_f + 2 * T * in_f + in_f * out_f)):
                 _lib.check(lib.te_linear_cpass_f32(_ptr(S), _ptr(Xc), _ptr(Wc), _ptr(out), T, in_f, out_f, st),
                            "te_linear_cpass_f32")
         return out.reshape(*lead, in_f)
     with _on_device(Xc) as lib:
         ws = _ws(lib.te_linear_relprop_workspace_bytes(T, in_f, out_f, var), Xc)
         if fwd:
-            _lib.check(lib.te_linear_relprop_fwd_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(Yc), _ptr(bc), _ptr(out), T, in_f,
-                                                     out_f, _ptr(ws), ws.numel(), _stream(Xc)),
-                       "te_linear_relprop_fwd_f32")
+            _lib.check(lib.te_linear_relprop_fwd_scaled_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc),
+                                                            _ptr(Yc), _ptr(bc), _ptr(out), T, in_f, out_f, _ptr(ws),
+                                                            ws.numel(), _stream(Xc)),
+                       "te_linear_relprop_fwd_scaled_f32")
         else:
             _lib.check(lib.te_linear_relprop_f32(_ptr(Rc), _ptr(Xc), _ptr(Wc), _ptr(out), T, in_f, out_f, float(alpha),
                                                  var, _ptr(ws), ws.numel(), _stream(Xc)), "te_linear_relprop_f32")
@@ -165,7 +204,8 @@ def matmul_relprop_av(R: Tensor, attn: Tensor, v: Tensor, out_scale: float = 1.0
     if cam_v.stride(-1) != 1:
         raise _lib.TeError("cam_v_out must have a contiguous last dim")
     cv_sb, cv_sh, cv_sn, _ = cam_v.stride()
-    with _on_device(attn) as lib:
+    with _on_device(attn) as lib, _timed("attention_av_rule", 4.0 * B * H * N * N * D,
+                                         4.0 * B * H * (2 * N * N + 5 * N * D)):
         ws = _ws(lib.te_matmul_relprop_av_workspace_bytes(B, H, N, D), attn)
         _lib.check(lib.te_matmul_relprop_av_fwd_f32(
             _ptr(R), r_sb, r_sh, r_sn, _ptr(attn), _ptr(v), v_sb, v_sh, v_sn, _ptr(zc), _ptr(cam_attn),
@@ -190,7 +230,8 @@ def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
     if cam_q.stride(-1) != 1 or cam_k.stride(-1) != 1:
         raise _lib.TeError("cam_q_out / cam_k_out must have a contiguous last dim")
     cq, ck = cam_q.stride(), cam_k.stride()
-    with _on_device(R) as lib:
+    with _on_device(R) as lib, _timed("attention_qk_rule", 4.0 * B * H * N * N * D,
+                                      4.0 * B * H * (2 * N * N + 4 * N * D)):
         ws = _ws(lib.te_matmul_relprop_qk_workspace_bytes(B, H, N, D), R)
         _lib.check(lib.te_matmul_relprop_qk_fwd_f32(
             _ptr(R), _ptr(q), q_sb, q_sh, q_sn, _ptr(k), k_sb, k_sh, k_sn, _ptr(zc),
@@ -201,9 +242,16 @@ def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
 
 
 # ---------------------------------------------------------------------------------------- a5
-def add_relprop(R: Tensor, X0: Tensor, X1: Tensor, variant="ours") -> Tuple[Tensor, Tensor]:
+# Model-internal Add rules hand their per-sample rescale to the consuming Clone / Linear kernels (one streaming pass
+# instead of two).  Tests flip this to run the two-pass rule on the same inputs.
+USE_DEFERRED_ADD = True
+
+
+def add_relprop(R: Tensor, X0: Tensor, X1: Tensor, variant="ours", deferred: bool = False):
     """Add.relprop with per-sample sums.  dim 0 is the batch.  X1 has X0's shape, or batch 1 (shared by
-    all samples), or is the BERT broadcast mask [B,1,1,N] against X0 [B,H,N,N]."""
+    all samples), or is the BERT broadcast mask [B,1,1,N] against X0 [B,H,N,N].
+    deferred=True (variant ours, same-shape operands): one streaming pass; returns two ``Deferred`` (unscaled tensor +
+    per-sample factor) for clone_relprop / linear_relprop to consume."""
     B = X0.shape[0]
     R, X0 = _c(R), _c(X0)
     n = X0[0].numel()
@@ -214,7 +262,7 @@ def add_relprop(R: Tensor, X0: Tensor, X1: Tensor, variant="ours") -> Tuple[Tens
             mask = mask.expand(B, N).contiguous()
         out0 = torch.empty_like(X0)
         out1 = torch.empty((B, 1, 1, N), dtype=torch.float32, device=X0.device)
-        with _on_device(X0) as lib:
+        with _on_device(X0) as lib, _timed("add_bcast_mask", 0.0, 4.0 * B * (3 * H * N * N + 2 * N)):
             ws = _ws(lib.te_add_bcast_relprop_workspace_bytes(B, H, N), X0)
             _lib.check(lib.te_add_bcast_relprop_f32(_ptr(R), _ptr(X0), _ptr(mask), _ptr(out0), _ptr(out1), B, H, N,
                                                     _variant(variant), _ptr(ws), ws.numel(), _stream(X0)),
@@ -228,24 +276,47 @@ def add_relprop(R: Tensor, X0: Tensor, X1: Tensor, variant="ours") -> Tuple[Tens
     else:
         raise _lib.TeError(f"Add.relprop: unsupported operand shapes {tuple(X0.shape)} + {tuple(X1.shape)}")
     out0, out1 = torch.empty_like(X0), torch.empty_like(X0)
-    with _on_device(X0) as lib:
+    var = _variant(variant)
+    x1_elems = n if x1_bs else n / B
+    if deferred and var == TE_VARIANT_OURS:
+        fac = torch.empty((B, 2), dtype=torch.float32, device=X0.device)
+        with _on_device(X0) as lib, _timed("add_deferred", 0.0, 4.0 * B * (4 * n + x1_elems)):
+            ws = _ws(lib.te_add_relprop_deferred_workspace_bytes(B, n), X0)
+            _lib.check(lib.te_add_relprop_deferred_f32(_ptr(R), _ptr(X0), _ptr(X1), _ptr(out0), _ptr(out1), _ptr(fac), B,
+                                                       n, x1_bs, _ptr(ws), ws.numel(), _stream(X0)),
+                       "te_add_relprop_deferred_f32")
+        return Deferred(out0, fac[:, 0]), Deferred(out1, fac[:, 1])
+    with _on_device(X0) as lib, _timed("add", 0.0, 4.0 * B * (4 * n + x1_elems)):
         ws = _ws(lib.te_add_relprop_workspace_bytes(B, n), X0)
         _lib.check(lib.te_add_relprop_f32(_ptr(R), _ptr(X0), _ptr(X1), _ptr(out0), _ptr(out1), B, n, x1_bs,
-                                          _variant(variant), _ptr(ws), ws.numel(), _stream(X0)), "te_add_relprop_f32")
+                                          var, _ptr(ws), ws.numel(), _stream(X0)), "te_add_relprop_f32")
     return out0, out1
 
 
 # ---------------------------------------------------------------------------------------- a6
-def clone_relprop(Rs: Sequence[Tensor], X: Tensor) -> Tensor:
+def clone_relprop(Rs: Sequence, X: Tensor) -> Tensor:
+    """Clone.relprop; relevance operands may be ``Deferred`` (their per-sample factor is applied inside the kernel)."""
     if len(Rs) not in (2, 3):
         raise _lib.TeError(f"Clone.relprop supports 2 or 3 aliases, got {len(Rs)}")
     X = _c(X)
-    Rs = [_c(r) for r in Rs]
+    pairs = [_split_deferred(r) for r in Rs]
+    Rs = [_c(r) for r, _ in pairs]
+    scales = [sc for _, sc in pairs]
     for r in Rs:
         if r.numel() != X.numel():
             raise _lib.TeError("Clone.relprop: relevance / input size mismatch")
     out = torch.empty_like(X)
-    with _on_device(X) as lib:
+    nb = 4.0 * X.numel() * (len(Rs) + 2)
+    if any(sc is not None for sc in scales):
+        B = X.shape[0]
+        sp = [(None, 0) if sc is None else (sc.data_ptr(), sc.stride(0)) for sc in scales] + [(None, 0)]
+        with _on_device(X) as lib, _timed("clone", 0.0, nb):
+            _lib.check(lib.te_clone_relprop_scaled_f32(_ptr(Rs[0]), sp[0][0], sp[0][1], _ptr(Rs[1]), sp[1][0], sp[1][1],
+                                                       _ptr(Rs[2]) if len(Rs) == 3 else None, sp[2][0], sp[2][1],
+                                                       _ptr(X), _ptr(out), B, X.numel() // B, _stream(X)),
+                       "te_clone_relprop_scaled_f32")
+        return out
+    with _on_device(X) as lib, _timed("clone", 0.0, nb):
         _lib.check(lib.te_clone_relprop_f32(_ptr(Rs[0]), _ptr(Rs[1]), _ptr(Rs[2]) if len(Rs) == 3 else None, _ptr(X),
                                             _ptr(out), X.numel(), _stream(X)), "te_clone_relprop_f32")
     return out
@@ -271,25 +342,41 @@ def gradcam_headmean(grad: Tensor, cam: Tensor, out: Optional[Tensor] = None) ->
     B, H, N, _ = cam.shape
     if out is None:
         out = torch.empty((B, N, N), dtype=torch.float32, device=cam.device)
-    with _on_device(cam) as lib:
+    with _on_device(cam) as lib, _timed("headmean", 0.0, 4.0 * B * (2 * H + 1) * N * N):
         _lib.check(lib.te_gradcam_headmean_f32(_ptr(grad), _ptr(cam), _ptr(out), B, H, N, _stream(cam)),
                    "te_gradcam_headmean_f32")
     return out
 
 
 # ---------------------------------------------------------------------------------------- a11
-def rollout(cams: Tensor, start_layer: int = 0, normalise: bool = False, cls_fixup: bool = False) -> Tensor:
-    """cams [L,B,N,N] -> joint [B,N,N] (compute_rollout_attention)."""
+# The generators consume row 0 of the rollout only: chain it as a row vector (te_rollout_f32 with TE_ROLLOUT_ROW0).
+# Tests flip this to run the full (N x N)(N x N) product chain and slice row 0 afterwards.
+USE_ROW0_CHAIN = True
+
+
+def rollout(cams: Tensor, start_layer: int = 0, normalise: bool = False, cls_fixup: bool = False,
+            row0_only: bool = False) -> Tensor:
+    """cams [L,B,N,N] -> joint [B,N,N] (compute_rollout_attention); row0_only=True -> joint[:, 0] as [B,N] (the only row
+    the generators read: ViT_LRP.py:369, ExplanationGenerator.py:58-59)."""
     cams = _c(cams)
     L, B, N, _ = cams.shape
-    joint = torch.empty((B, N, N), dtype=torch.float32, device=cams.device)
     flags = (TE_ROLLOUT_NORMALISE if normalise else 0) | (TE_ROLLOUT_CLS_FIXUP if cls_fixup else 0) | \
         (TE_IMPL_SIMPLE if FORCE_SIMPLE else 0)
-    with _on_device(cams) as lib:
+    if row0_only and USE_ROW0_CHAIN and not FORCE_SIMPLE and N <= 1024:
+        row = torch.empty((B, N), dtype=torch.float32, device=cams.device)
+        with _on_device(cams) as lib, _timed("rollout_row0_chain", 2.0 * (L - start_layer) * B * N * N,
+                                             4.0 * (L - start_layer) * B * N * N):
+            ws = _ws(lib.te_rollout_row0_workspace_bytes(B, N), cams)
+            _lib.check(lib.te_rollout_f32(_ptr(cams), L, int(start_layer), B, N, flags | TE_ROLLOUT_ROW0, _ptr(row),
+                                          _ptr(ws), ws.numel(), _stream(cams)), "te_rollout_f32")
+        return row
+    joint = torch.empty((B, N, N), dtype=torch.float32, device=cams.device)
+    with _on_device(cams) as lib, _timed("rollout_matrix_chain", 2.0 * (L - 1 - start_layer) * B * N * N * N,
+                                         4.0 * (L - start_layer) * B * N * N):
         ws = _ws(lib.te_rollout_workspace_bytes(L, B, N), cams)
         _lib.check(lib.te_rollout_f32(_ptr(cams), L, int(start_layer), B, N, flags, _ptr(joint), _ptr(ws), ws.numel(),
                                       _stream(cams)), "te_rollout_f32")
-    return joint
+    return joint[:, 0] if row0_only else joint
 
 
 # ---------------------------------------------------------------------------------------- 8f.3 Conv2d z^B

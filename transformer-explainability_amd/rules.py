@@ -41,6 +41,12 @@ def forward_hook(self, input, output):
     else:
         self.X = input[0].detach()
     self.Y = output
+    # the rules that take Z from the cached forward output (Linear, einsum, MatMul) only do so while that tensor
+    # -- and the weight that produced it -- are exactly what the forward pass wrote (see _cached_y)
+    self._y_version = output._version if torch.is_tensor(output) else None
+    w = getattr(self, "weight", None)
+    b = getattr(self, "bias", None)
+    self._w_version = (w._version if torch.is_tensor(w) else None, b._version if torch.is_tensor(b) else None)
 
 
 class StopRelprop(Exception):
@@ -49,9 +55,21 @@ class StopRelprop(Exception):
 
 
 def _cached_y(module):
-    """The forward output forward_hook stored (the product whose rule is being evaluated), or None."""
+    """The forward output forward_hook stored (the product whose rule is being evaluated), or None.
+
+    self.Y is the LIVE output tensor (an alias, like the reference's), so an in-place op after the layer
+    (``ReLU(inplace=True)``, ``x += ...``) or an optimizer step on the weight would silently change what Z is derived
+    from, whereas the reference recomputes Z from X and W.  forward_hook records the tensors' version counters; a
+    mismatch means "modified since the forward pass" and the rule falls back to recomputing Z itself."""
     y = getattr(module, "Y", None)
-    return y if torch.is_tensor(y) else None
+    if not torch.is_tensor(y) or getattr(module, "_y_version", None) != y._version:
+        return None
+    w = getattr(module, "weight", None)
+    b = getattr(module, "bias", None)
+    now = (w._version if torch.is_tensor(w) else None, b._version if torch.is_tensor(b) else None)
+    if getattr(module, "_w_version", now) != now:
+        return None
+    return y
 
 
 class RelProp(nn.Module):
@@ -104,7 +122,9 @@ class Linear(nn.Linear, RelProp):
     def relprop(self, R, alpha):
         # self.Y (the forward output, cached by forward_hook like the reference does) lets the kernel derive
         # Z = X+ W+^T + X- W-^T from one product instead of two
-        Y = self.Y if (torch.is_tensor(getattr(self, "Y", None)) and self.Y.shape[:-1] == self.X.shape[:-1]) else None
+        Y = _cached_y(self)
+        if Y is not None and Y.shape[:-1] != self.X.shape[:-1]:
+            Y = None
         return ops.linear_relprop(R, self.X, self.weight.detach(), alpha=alpha, variant=self.variant, Y=Y,
                                   bias=self.bias)
 
@@ -116,8 +136,12 @@ class Add(RelProp):
     def forward(self, inputs):
         return torch.add(*inputs)
 
-    def relprop(self, R, alpha):
-        a, b = ops.add_relprop(R, self.X[0], self.X[1], variant=self.variant)
+    def relprop(self, R, alpha, deferred=False):
+        # deferred=True (model-internal call sites only): the per-sample rescale of layers_ours.py:117-118 travels with
+        # the two outputs as an ``ops.Deferred`` and is applied inside the consuming Clone / Linear kernels -- the
+        # rule then streams its operands once instead of twice; ``.materialise()`` is bitwise the plain result
+        a, b = ops.add_relprop(R, self.X[0], self.X[1], variant=self.variant,
+                               deferred=deferred and ops.USE_DEFERRED_ADD and self.X[0].shape == self.X[1].shape)
         return [a, b]
 
 
@@ -191,13 +215,25 @@ class IndexSelect(RelProp):
     def forward(self, inputs, dim, indices):
         self.__setattr__('dim', dim)
         self.__setattr__('indices', indices)
+        # a host copy of a single index, taken where it is free: python ints and CPU tensors here, a device tensor
+        # once per tensor object (models pass the same buffer every call) -- relprop then never synchronises and is
+        # capturable in a HIP graph
+        if not torch.is_tensor(indices):
+            self._index_host = int(indices)
+        elif indices.numel() == 1 and (not indices.is_cuda or getattr(self, "_index_src", None) is not indices):
+            if not (indices.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._index_host = int(indices)
+                self._index_src = indices
         return torch.index_select(inputs, dim, indices.reshape(-1) if torch.is_tensor(indices) else indices)
 
     def relprop(self, R, alpha):
         idx = self.indices
         if self.dim != 1 or self.X.dim() != 3 or (torch.is_tensor(idx) and idx.numel() != 1):
             raise NotImplementedError("IndexSelect.relprop: only dim=1 with a single index is accelerated")
-        return ops.index_select_relprop(R, self.X, int(idx))      # (device sync if idx lives on the GPU)
+        host = getattr(self, "_index_host", None)
+        if host is None or (torch.is_tensor(idx) and getattr(self, "_index_src", idx) is not idx):
+            host = int(idx)                                        # (device sync; not capturable)
+        return ops.index_select_relprop(R, self.X, host)
 
 
 class Sequential(nn.Sequential):

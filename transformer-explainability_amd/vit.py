@@ -172,10 +172,10 @@ def make_vit_module(L):
 
         def relprop(self, cam, **kwargs):
             """ViT_LRP.py:203-213 (LayerNorm rules are the identity)."""
-            cam1, cam2 = self.add2.relprop(cam, **kwargs)
+            cam1, cam2 = self.add2.relprop(cam, deferred=True, **kwargs)
             cam2 = self.mlp.relprop(cam2, **kwargs)
             cam = self.clone2.relprop((cam1, cam2), **kwargs)
-            cam1, cam2 = self.add1.relprop(cam, **kwargs)
+            cam1, cam2 = self.add1.relprop(cam, deferred=True, **kwargs)
             cam2 = self.attn.relprop(cam2, **kwargs)
             return self.clone1.relprop((cam1, cam2), **kwargs)
 
@@ -189,13 +189,16 @@ def make_vit_module(L):
             alpha = kwargs.get("alpha", 1)
             var = self.add2.variant
             cls = lambda t: t[:, :1]                                             # noqa: E731
-            c1, c2 = ops.add_relprop(cam_cls, cls(self.add2.X[0]), cls(self.add2.X[1]), variant=var)
+            dfr = ops.USE_DEFERRED_ADD
+            c1, c2 = ops.add_relprop(cam_cls, cls(self.add2.X[0]), cls(self.add2.X[1]), variant=var, deferred=dfr)
             lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,     # noqa: E731
                                                   Y=cls(m.Y), bias=m.bias)
             c2 = lin(lin(c2, self.mlp.fc2), self.mlp.fc1)
             cam = ops.clone_relprop((c1, c2), cls(self.clone2.X))
-            c1, c2 = ops.add_relprop(cam, cls(self.add1.X[0]), cls(self.add1.X[1]), variant=var)
+            c1, c2 = ops.add_relprop(cam, cls(self.add1.X[0]), cls(self.add1.X[1]), variant=var, deferred=dfr)
             c2 = lin(c2, self.attn.proj)
+            if isinstance(c1, ops.Deferred):
+                c1 = c1.materialise()
             B, N, C = self.clone1.X.shape
             dense = torch.zeros((2, B, N, C), dtype=c2.dtype, device=c2.device)
             dense[0, :, 0] = c1[:, 0]
@@ -340,8 +343,7 @@ def make_vit_module(L):
                 for i, blk in enumerate(self.blocks):
                     if i >= start_layer or not prune:       # (the rollout reads layers >= start_layer only)
                         ops.gradcam_headmean(blk.attn.get_attn_gradients(), blk.attn.get_attn_cam(), out=stack[i])
-                joint = ops.rollout(stack, start_layer=start_layer, normalise=False)
-                return joint[:, 0, 1:]
+                return ops.rollout(stack, start_layer=start_layer, normalise=False, row0_only=True)[:, 1:]
 
             if method in ("last_layer", "second_layer"):
                 blk = self.blocks[-1] if method == "last_layer" else self.blocks[1]
