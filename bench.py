@@ -1,35 +1,42 @@
 #!/usr/bin/env python
-"""bench.py -- relevance maps/sec for ViT-B/16 224^2 at batch 64 per GPU (BASELINE.json metric).
+"""bench.py -- relevance maps/sec for ViT-B/16 224^2 at batch 64 per GPU (BASELINE.json metric; configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config vit_b16_224 | vit_l16_384 | bert_base_512]
 
-A "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
-stock PyTorch-ROCm forward + attention-gradient backward, then the HIP relprop rules, the
-gradient x relevance head-mean and the rollout chain (LRP.generate_LRP, method
-"transformer_attribution", start_layer 1 as baselines/ViT/imagenet_seg_eval.py:196 of the reference calls
-it), fp32 end to end.  All 12 blocks are propagated; the only shortcuts are exact or rounding-level:
-the inhibitor half is dead at alpha = 1, the last block's dense rules run on the class-token row they are confined to,
-and the Z-pass of Linear.relprop reuses the forward output X W^T + b instead of recomputing it.
+``--gpus N`` with N > 1 launches N ranks by itself (one process per GPU under ``torch.distributed.run`` on
+127.0.0.1) when it is not already running under a launcher; under one (RANK in the environment, as the driver starts
+it) it asserts WORLD_SIZE == N.  It refuses to run with fewer visible GPUs than ranks.
 
-Weak scaling: every rank runs the same batch size on its own images; the only communication is one
-all_gather (RCCL) of the finished [B,196] maps of the last step, inside the timed region.
+A "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM: stock PyTorch-ROCm
+forward + attention-gradient backward, then the HIP relprop rules, the gradient x relevance head-mean and the rollout
+chain (LRP.generate_LRP, method "transformer_attribution", start_layer 1 as baselines/ViT/imagenet_seg_eval.py:196 of
+the reference calls it), fp32 end to end.  All blocks are propagated; the only shortcuts are exact or rounding-level
+(DESIGN.md section 3).  Every rank replays its step from a HIP graph captured BEFORE the process group exists (so
+RCCL's threads never see an open capture); ONE step of the timed region runs eagerly with a HIP-event pair around
+every C-ABI call of the relprop path -- the source of the roofline block.
 
-The JSON line also carries
-  roofline      the dominant kernel (Linear.relprop C-pass, fp32 MFMA): algorithmic FLOPs per launch over
-                the launch duration measured with HIP events on the launch stream, during the timed steps
-  cpu_baseline  the same path on the host cores of this box: stock PyTorch CPU fwd/bwd + the CPU oracle's
-                relprop (kind "port"), or the reference itself when /root/reference exists (kind
-                "reference"); rank 0, N = 1 only, bounded to a few maps
+Weak scaling: every rank runs the same batch size on its own inputs; the only communication is one all_gather (RCCL)
+of the finished maps of the last step, inside the timed region.
+
+The JSON line carries
+  roofline      dominant kernel (Linear.relprop C-pass, fp32 MFMA) + ``kernels``: one entry per relprop kernel group
+                with its ALGORITHMIC FLOPs / bytes per launch, the average launch duration from
+                HIP events on the launch stream, and the fraction of the roofline that bounds it
+  cpu_baseline  THE REFERENCE ITSELF (imported from /root/reference, or from its staged copy oracle/_ref -- see
+                scripts/stage_reference.py) timed on the host cores of this box: >= 5 maps after one warm-up with all
+                usable cores, plus the 1-thread figure; kind "port" (our CPU forward + the oracle) only if neither
+                exists.  Rank 0, N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
 import contextlib
 import faulthandler
+import fcntl
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,10 +44,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 _T0 = time.perf_counter()
+
+CONFIGS = {
+    # name: (BASELINE.json configs index, default batch per GPU, description)
+    "vit_b16_224": (1, 64, "ViT-B/16 224^2"),
+    "vit_l16_384": (2, 32, "ViT-L/16 384^2"),
+    "bert_base_512": (3, 32, "BERT-base 512 tokens"),
+}
 
 
 def log(msg):
@@ -48,110 +61,18 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def host_cores():
-    """Cores this process may actually run on (cgroup / affinity aware), capped: torch CPU GEMMs stop scaling
-    long before a 100+ core host is filled and oversubscribing a container quota is catastrophic."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:   # cgroup v2 CPU quota
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(n, 32))
-
-
-class KernelTimer:
-    """Brackets single kernel launches with HIP events recorded on torch's current stream (the stream
-    the C ABI launches on).  Events are resolved after the timed region's final synchronise."""
-
-    def __init__(self):
-        self.records = []          # (name, flops, start_event, end_event)
-        self.enabled = False
-
-    @contextlib.contextmanager
-    def __call__(self, name, flops):
-        if not self.enabled:
-            yield
-            return
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        yield
-        e.record()
-        self.records.append((name, flops, s, e))
-
-    def summary(self, name):
-        rows = [(f, s.elapsed_time(e) * 1e-3) for n, f, s, e in self.records if n == name]
-        if not rows:
-            return None
-        flops = sum(f for f, _ in rows)
-        secs = sum(t for _, t in rows)
-        return {"launches": len(rows), "avg_us": secs / len(rows) * 1e6, "tflops": flops / secs / 1e12,
-                "flops_per_launch_avg": flops / len(rows)}
-
-
-def cpu_baseline(args, model_cpu_state, n_maps=3):
-    """Time the CPU path on this box's host cores: one sample at a time (the reference is batch-1)."""
-    from oracle import ref_harness as rh
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads (os.cpu_count() = {os.cpu_count()})")
-    x = torch.stack([synthetic_image(i) for i in range(n_maps + 1)])
-    if rh.reference_available() and args.cpu_baseline != "port":
-        mods = rh.load_reference_vit()
-        model = mods["ViT_LRP"].vit_base_patch16_224(pretrained=False).eval()
-        model.load_state_dict(model_cpu_state)
-        gen = mods["gen"].LRP(model)
-        times = []
-        for i in range(n_maps + 1):
-            t0 = time.perf_counter()
-            gen.generate_LRP(x[i:i + 1], method="transformer_attribution", start_layer=args.start_layer)
-            times.append(time.perf_counter() - t0)
-            log(f"cpu_baseline(reference) map {i}: {times[-1]:.2f} s")
-        kind = "reference"
-    else:
-        from transformer_explainability_amd import vit
-        from oracle import relprop_oracle as O
-        from oracle.model_cache import vit_cache_from_model
-        model = vit.vit_base_patch16_224().eval()
-        model.load_state_dict(model_cpu_state)
-        times = []
-        for i in range(n_maps + 1):
-            t0 = time.perf_counter()
-            out = model(x[i:i + 1])
-            oh = torch.zeros_like(out)
-            oh.scatter_(1, out.argmax(-1, keepdim=True), 1.0)
-            grads = torch.autograd.grad((oh * out).sum(), [b.attn.get_attn() for b in model.blocks])
-            for b, g in zip(model.blocks, grads):
-                b.attn.save_attn_gradients(g)
-            O.vit_relprop(oh, vit_cache_from_model(model), num_heads=12, start_layer=args.start_layer)
-            times.append(time.perf_counter() - t0)
-            log(f"cpu_baseline(port) map {i}: {times[-1]:.2f} s")
-        kind = "port"
-    times = sorted(times[1:])
-    med = times[len(times) // 2]
-    return {"value": 1.0 / med, "unit": "maps/s", "cores": cores, "kind": kind,
-            "sample": f"{n_maps} ViT-B/16 224^2 maps, batch 1, after 1 warm-up; median {med:.3f} s/map, "
-                      f"torch CPU fp32 with {cores} threads"}
-
-
-def synthetic_image(global_index, shape=(3, 224, 224), seed=1):
-    g = torch.Generator().manual_seed(seed * 1_000_003 + global_index)
-    return torch.randn(shape, generator=g, dtype=torch.float32)
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--start-layer", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="vit_b16_224",
+                    help="vit_b16_224 = BASELINE.json's headline (configs[1]); the others are configs[2] / configs[3]")
+    ap.add_argument("--batch", type=int, default=0, help="inputs per GPU per step (0 = the configuration's own)")
+    ap.add_argument("--start-layer", type=int, default=None,
+                    help="default: 1 for ViT (imagenet_seg_eval.py:196), 0 for BERT (every layer reaches the map)")
     ap.add_argument("--cpu-baseline", choices=["auto", "port", "off"], default="auto")
+    ap.add_argument("--cpu-maps", type=int, default=5, help="timed maps of the all-cores cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="micro-batches in flight on separate HIP streams")
     ap.add_argument("--graph", choices=["on", "off"], default="on",
@@ -164,49 +85,385 @@ def main():
                     help="skip the relprop rules and attention gradients of the blocks below --start-layer (their "
                          "attn_cam never reaches the map); off = every block, as the reference does")
     ap.add_argument("--overlap-backward", choices=["on", "off"], default="off",
-                    help="run the relprop rules on a side stream beside the attention-gradient backward pass (they are "
-                         "independent until the head-mean / rollout tail); the roofline probe step stays serial")
+                    help="run the relprop rules on a side stream beside the attention-gradient backward pass")
     ap.add_argument("--inflight", type=int, default=1,
-                    help="consecutive steps (batches) in flight, each on its own HIP stream: the forward/backward of "
-                         "step k+1 overlaps the relprop of step k")
-    args = ap.parse_args()
-    faulthandler.enable()
-    faulthandler.dump_traceback_later(600, repeat=True, file=sys.stderr)   # a stuck run leaves a stack trace
+                    help="consecutive steps (batches) in flight, each on its own HIP stream (eager launches)")
+    ap.add_argument("--producers", choices=["stock", "fused"], default="stock",
+                    help="fused: hand-written attention-forward producer kernels where available (SURVEY.md 8f.1)")
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def build_once():
+    """__graft_entry__.build() under an exclusive file lock: every rank may call it, one compiles, the rest wait and
+    find the library up to date (no process group needed, so it can run before init_process_group)."""
     import __graft_entry__
-    import transformer_explainability_amd as te
-    from transformer_explainability_amd import ops, parallel, vit
-    from transformer_explainability_amd.generators import LRP
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            __graft_entry__.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
-    rank, world, local = parallel.init_distributed()
-    if rank == 0:
-        __graft_entry__.build()
-    if world > 1:
-        torch.distributed.barrier()
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) and relay their exit code."""
+    import torch
+    rig = "TE_DEVICE_OVERRIDE" in os.environ or os.environ.get("TE_DIST_BACKEND") == "gloo"
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < args.gpus and not rig:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {visible} GPU(s) visible -- refusing to run {args.gpus} ranks on "
+                 f"fewer devices (set TE_DIST_BACKEND=gloo + TE_DEVICE_OVERRIDE=0 for the one-GPU test rig)")
+    build_once()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ----------------------------------------------------------------------------------------------------- kernel timer
+class KernelTimer:
+    """Brackets single C-ABI calls with HIP events recorded on torch's current stream (the stream the C ABI launches
+    on).  Events are resolved after the timed region's final synchronise."""
+
+    def __init__(self):
+        self.records = []          # (name, flops, bytes, start_event, end_event)
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def __call__(self, name, flops, nbytes):
+        if not self.enabled:
+            yield
+            return
+        import torch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        yield
+        e.record()
+        self.records.append((name, flops, nbytes, s, e))
+
+    def names(self):
+        return sorted({r[0] for r in self.records})
+
+    def summary(self, name):
+        """Launches of `name` carrying at least half of the largest launch's work (the class-token-only launches of the
+        last block move ~1/N of it and would only dilute the averages)."""
+        rows = [(f, b, s.elapsed_time(e) * 1e-3) for n, f, b, s, e in self.records if n == name]
+        if not rows:
+            return None
+        work = [max(f / (MFMA_F32_PEAK_TFLOPS * 1e12), b / (HBM_PEAK_TBS * 1e12)) for f, b, _ in rows]
+        keep = [r for r, w in zip(rows, work) if w >= 0.5 * max(work)]
+        n = len(keep)
+        flops, nbytes, secs = (sum(r[i] for r in keep) for i in range(3))
+        return {"launches": n, "launches_dropped_as_small": len(rows) - n, "avg_us": secs / n * 1e6,
+                "flops_per_launch": flops / n, "bytes_per_launch": nbytes / n,
+                "tflops": flops / secs / 1e12, "tbs": nbytes / secs / 1e12}
+
+
+KERNEL_GROUPS = {
+    # timer name: (device kernels, reference rule)
+    "linear_cpass": ("linear_k2_kernel<0,false,false>", "Linear.relprop C-pass, layers_ours.py:220-225"),
+    "linear_zpass_fwd": ("linear_k1_kernel<ZM_FWD>", "Linear.relprop Z-pass from the forward output, layers_ours.py:216-219"),
+    "linear_zpass": ("linear_k1_kernel<ZM_OURS>", "Linear.relprop Z-pass (two products), layers_ours.py:216-219"),
+    "attention_av_rule": ("av_row_kernel + col_kernel", "einsum 'bhij,bhjd->bhid' / MatMul rule, layers_ours.py:48-60"),
+    "attention_qk_rule": ("qk_row_kernel + col_kernel", "einsum 'bhid,bhjd->bhij' / MatMul rule, layers_ours.py:48-60"),
+    "attention_fused_rules": ("attn_rules_kernel", "both attention rules of a ViT block in one pass, ViT_LRP.py:157-173"),
+    "add_deferred": ("add_deferred_kernel + add_factors_kernel", "Add.relprop (one pass; rescale applied by the "
+                                                                 "consumers), layers_ours.py:97-120"),
+    "add": ("add_sums_kernel + add_apply_kernel", "Add.relprop, layers_ours.py:97-120"),
+    "add_bcast_mask": ("addb_sums + addb_finalize + addb_apply", "Add.relprop with the BERT mask operand, BERT.py:386-388"),
+    "clone": ("clone_kernel / clone_scaled_kernel", "Clone.relprop, layers_ours.py:151-169"),
+    "headmean": ("headmean_flat_kernel", "mean_h max(grad * attn_cam, 0), ViT_LRP.py:359-366"),
+    "rollout_row0_chain": ("rollout_row_step_kernel x (L - start) + finish", "compute_rollout_attention row 0, "
+                                                                            "ViT_LRP.py:38-49,369"),
+    "rollout_matrix_chain": ("rollout_prep + rollout_bmm_mfma_kernel x (L-1-start)", "compute_rollout_attention"),
+}
+
+
+def kernel_table(timer):
+    out = []
+    for name in timer.names():
+        s = timer.summary(name)
+        if not s:
+            continue
+        t = s["avg_us"] * 1e-6
+        t_f = s["flops_per_launch"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        t_b = s["bytes_per_launch"] / (HBM_PEAK_TBS * 1e12)
+        bound = "mfma" if t_f >= t_b else "hbm"
+        kern, rule = KERNEL_GROUPS.get(name, (name, ""))
+        row = {"name": name, "kernels": kern, "rule": rule, "bound": bound, "launches": s["launches"],
+               "avg_us": round(s["avg_us"], 2),
+               "algorithmic_flops_per_launch": s["flops_per_launch"], "algorithmic_bytes_per_launch": s["bytes_per_launch"],
+               "achieved": round(s["tflops"] if bound == "mfma" else s["tbs"], 4),
+               "peak": MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_TBS,
+               "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": round(max(t_f, t_b) / t, 4)}
+        out.append(row)
+    out.sort(key=lambda r: -r["avg_us"] * r["launches"])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------- workloads
+def synthetic_image(global_index, shape=(3, 224, 224), seed=1):
+    import torch
+    g = torch.Generator().manual_seed(seed * 1_000_003 + global_index)
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def synthetic_tokens(global_index, n_tokens=512, seed=1):
+    import torch
+    g = torch.Generator().manual_seed(seed * 1_000_003 + global_index)
+    return torch.randint(1000, 20000, (n_tokens,), generator=g)
+
+
+class Workload:
+    """Model + resident inputs + the step function of one BASELINE.json configuration."""
+
+    def __init__(self, args, rank, dev):
+        import torch
+        from transformer_explainability_amd import bert, vit
+        from transformer_explainability_amd.generators import LRP, Generator
+        self.args, self.name = args, args.config
+        _, self.B, self.title = CONFIGS[args.config]
+        if args.batch:
+            self.B = args.batch
+        B = self.B
+        torch.manual_seed(0)
+        if args.config.startswith("vit"):
+            if args.config == "vit_b16_224":
+                model, side = vit.vit_base_patch16_224().eval(), 224
+            else:
+                model, side = vit.vit_large_patch16_224(img_size=384).eval(), 384
+            with torch.no_grad():          # non-trivial biases / LayerNorm scales so every path is exercised
+                for _, p in model.named_parameters():
+                    if p.dim() == 1:
+                        p.add_(0.02 * torch.randn_like(p))
+            self.cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+            self.start_layer = 1 if args.start_layer is None else args.start_layer
+            self.inputs = (torch.stack([synthetic_image(rank * B + i, (3, side, side)) for i in range(B)]).to(dev),)
+            self.model = model.to(dev)
+            self.gen = LRP(self.model, streams=args.streams, overlap_backward=(args.overlap_backward == "on"),
+                           prune=(args.prune == "on"))
+            self.tokens = (side // 16) ** 2 + 1
+            self.out_cols = self.tokens - 1
+            self.blocks = len(model.blocks)
+            self.unit, self.noun = "maps/s", "maps"
+            self.side = side
+        else:
+            model = bert.BertForSequenceClassification(bert.BertConfigLite(num_labels=2)).eval()
+            with torch.no_grad():
+                for _, p in model.named_parameters():
+                    if p.dim() == 1:
+                        p.add_(0.02 * torch.randn_like(p))
+            self.cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+            self.start_layer = 0 if args.start_layer is None else args.start_layer
+            ids = torch.stack([synthetic_tokens(rank * B + i) for i in range(B)]).to(dev)
+            mask = torch.ones(B, 512)
+            mask[::2, 512 - 64:] = 0       # half of the batch padded: the broadcast-mask Add rule is exercised
+            self.inputs = (ids, mask.to(dev))
+            self.model = model.to(dev)
+            self.gen = Generator(self.model, prune=(args.prune == "on"))
+            self.tokens, self.out_cols, self.blocks = 512, 512, 12
+            self.unit, self.noun = "sequences/s", "sequences"
+            self.side = None
+
+    def eager(self, *inputs):
+        if self.name.startswith("vit"):
+            return self.gen.generate_LRP(inputs[0], method="transformer_attribution", start_layer=self.start_layer)
+        return self.gen.generate_LRP(input_ids=inputs[0], attention_mask=inputs[1], start_layer=self.start_layer)
+
+    def eager_serial(self, *inputs):
+        """The probe step: kernel durations must be a kernel's own, so no relprop-beside-backward overlap."""
+        ov = getattr(self.gen, "overlap_backward", False)
+        if ov:
+            self.gen.overlap_backward = False
+        try:
+            return self.eager(*inputs)
+        finally:
+            if ov:
+                self.gen.overlap_backward = True
+
+
+# ----------------------------------------------------------------------------------------------------- cpu baseline
+def usable_cores():
+    """Cores this process may actually run on (affinity and cgroup-quota aware), uncapped."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:   # cgroup v2 CPU quota
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, wl):
+    """Time the CPU path on this box's host cores, one sample at a time (the reference is batch-1): all usable cores
+    (1 warm-up + args.cpu_maps maps, median), a 32-thread leg when the host has more cores than that (torch's CPU GEMMs
+    on M = 197 rows stop scaling long before a 100+ core host is filled; the best leg is the reported value), and the
+    1-thread figure (1 warm-up + 2 maps)."""
+    import torch
+    from oracle import ref_harness as rh
+    cores = usable_cores()
+    kind = "reference" if (rh.reference_available() and args.cpu_baseline != "port") else "port"
+    log(f"cpu_baseline: kind {kind} ({rh.reference_origin()}), {cores} usable cores (os.cpu_count() = {os.cpu_count()}), "
+        f"{cpu_model_string()}")
+    n_in = max(args.cpu_maps, 2) + 1
+    is_vit = wl.name.startswith("vit")
+    if is_vit:
+        xs = torch.stack([synthetic_image(i, (3, wl.side, wl.side)) for i in range(n_in)])
+    else:
+        xs = torch.stack([synthetic_tokens(i) for i in range(n_in)])
+        ms = torch.ones(n_in, 512)
+        ms[::2, 512 - 64:] = 0
+
+    if kind == "reference":
+        if is_vit:
+            mods = rh.load_reference_vit()
+            if wl.name == "vit_b16_224":
+                model = mods["ViT_LRP"].vit_base_patch16_224(pretrained=False).eval()
+            else:
+                model = mods["ViT_LRP"].vit_large_patch16_224(pretrained=False, img_size=384).eval()
+            model.load_state_dict(wl.cpu_state)
+            gen = mods["gen"].LRP(model)
+            run = lambda i: gen.generate_LRP(xs[i:i + 1], method="transformer_attribution",    # noqa: E731
+                                             start_layer=wl.start_layer)
+            what = "reference LRP.generate_LRP (baselines/ViT/ViT_explanation_generator.py:25-41)"
+        else:
+            mods = rh.load_reference_bert()
+            from transformers import BertConfig
+            cfg = BertConfig(num_labels=2)
+            cfg.return_dict = False
+            model = mods["cls"].BertForSequenceClassification(cfg).eval()
+            model.load_state_dict(wl.cpu_state, strict=False)
+            gen = mods["gen"].Generator(model)
+            run = lambda i: gen.generate_LRP(input_ids=xs[i:i + 1], attention_mask=ms[i:i + 1],   # noqa: E731
+                                             start_layer=wl.start_layer)
+            what = "reference Generator.generate_LRP (BERT_explainability/modules/BERT/ExplanationGenerator.py:28-59)"
+    else:
+        from oracle import relprop_oracle as O
+        from oracle.model_cache import bert_cache_from_model, vit_cache_from_model
+        from transformer_explainability_amd import bert, vit
+        if is_vit:
+            model = (vit.vit_base_patch16_224() if wl.name == "vit_b16_224"
+                     else vit.vit_large_patch16_224(img_size=384)).eval()
+            model.load_state_dict(wl.cpu_state)
+            heads = model.blocks[0].attn.num_heads
+
+            def run(i):
+                out = model(xs[i:i + 1])
+                oh = torch.zeros_like(out)
+                oh.scatter_(1, out.argmax(-1, keepdim=True), 1.0)
+                grads = torch.autograd.grad((oh * out).sum(), [b.attn.get_attn() for b in model.blocks])
+                for b, g in zip(model.blocks, grads):
+                    b.attn.save_attn_gradients(g)
+                return O.vit_relprop(oh, vit_cache_from_model(model), num_heads=heads, start_layer=wl.start_layer)["map"]
+        else:
+            model = bert.BertForSequenceClassification(bert.BertConfigLite(num_labels=2)).eval()
+            model.load_state_dict(wl.cpu_state)
+
+            def run(i):
+                out = model(input_ids=xs[i:i + 1], attention_mask=ms[i:i + 1])[0]
+                oh = torch.zeros_like(out)
+                oh.scatter_(1, out.argmax(-1, keepdim=True), 1.0)
+                layers = model.bert.encoder.layer
+                grads = torch.autograd.grad((oh * out).sum(), [l.attention.self.get_attn() for l in layers])
+                for l, g in zip(layers, grads):
+                    l.attention.self.save_attn_gradients(g)
+                return O.bert_relprop(oh, bert_cache_from_model(model), num_heads=12, start_layer=wl.start_layer)["map"]
+        what = "our CPU forward/backward + the CPU oracle's relprop (no reference checkout or stage on this host)"
+
+    def leg(threads, n_maps):
+        torch.set_num_threads(threads)
+        times = []
+        for i in range(n_maps + 1):
+            t0 = time.perf_counter()
+            run(i % n_in)
+            times.append(time.perf_counter() - t0)
+            log(f"cpu_baseline({kind}, {threads} threads) {wl.noun[:-1]} {i}: {times[-1]:.2f} s")
+        times = sorted(times[1:])
+        return times[len(times) // 2]
+
+    legs = {cores: leg(cores, args.cpu_maps)}
+    if cores > 48:
+        legs[32] = leg(32, args.cpu_maps)
+    best = min(legs, key=legs.get)
+    # the 1-thread figure (BASELINE.md section 3) for the headline configuration only: a ViT-L / BERT-512 map takes
+    # minutes on one thread
+    one = None
+    if wl.name == "vit_b16_224":
+        one = leg(1, 2) if cores > 1 else legs[cores]
+    torch.set_num_threads(cores)
+    return {"value": 1.0 / legs[best], "unit": wl.unit, "cores": best, "kind": kind,
+            "cpu_model": cpu_model_string(), "usable_cores": cores,
+            "seconds_per_unit_by_threads": {str(k): round(v, 4) for k, v in sorted(legs.items())},
+            "one_thread": None if one is None else {"value": 1.0 / one, "seconds_per_unit": round(one, 4),
+                                                    "sample": "2 after 1 warm-up"},
+            "sample": f"{what}: {args.cpu_maps} {wl.title} {wl.noun}, batch 1, after 1 warm-up; median "
+                      f"{legs[best]:.3f} s each with {best} torch threads, fp32"}
+
+
+# -------------------------------------------------------------------------------------------------------------- main
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)                      # does not return
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(900, repeat=True, file=sys.stderr)   # a stuck run leaves a stack trace
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} is running under a launcher with WORLD_SIZE={world}: they must agree")
+    build_once()
+    import transformer_explainability_amd as te
+    from transformer_explainability_amd import ops, parallel
+    from transformer_explainability_amd.generators import GraphedCall
+
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    rig = "TE_DEVICE_OVERRIDE" in os.environ
+    if torch.cuda.device_count() < world and not rig:
+        sys.exit(f"rank {rank}: {torch.cuda.device_count()} GPU(s) visible for {world} ranks")
     te._lib.require_device()
-    dev = torch.device("cuda", int(os.environ.get("TE_DEVICE_OVERRIDE", local)))   # (override: test rigs with one GPU)
+    dev = torch.device("cuda", int(os.environ.get("TE_DEVICE_OVERRIDE", local)))   # (override: one-GPU test rig)
     torch.cuda.set_device(dev)
     tuned = False
     if args.tuned_gemms == "on":
         tuned = te.enable_tuned_gemms()
     elif args.tuned_gemms == "tune":
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         tuned = te.enable_tuned_gemms(os.path.join(ROOT, "gpurun_out", f"tunableop_gfx950_rank{rank}.csv"), tune=True)
+    if args.producers == "fused":
+        ops.USE_FUSED_PRODUCERS = True
 
-    torch.manual_seed(0)
-    model = vit.vit_base_patch16_224().eval()
-    with torch.no_grad():          # non-trivial biases / LayerNorm scales so every path is exercised
-        for n_, p in model.named_parameters():
-            if p.dim() == 1:
-                p.add_(0.02 * torch.randn_like(p))
-    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
-    model.to(dev)
-    B = args.batch
-    x = torch.stack([synthetic_image(rank * B + i) for i in range(B)]).to(dev)
-    lrp = LRP(model, streams=args.streams, overlap_backward=(args.overlap_backward == "on"),
-              prune=(args.prune == "on"))
-    log(f"rank {rank}/{world}: model + {B} images resident on {dev}")
+    wl = Workload(args, rank, dev)
+    B = wl.B
+    log(f"rank {rank}/{world}: {wl.title} model + {B} inputs resident on {dev}")
 
     timer = KernelTimer()
     if not args.no_roofline:
@@ -215,57 +472,54 @@ def main():
     lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
 
+    # The graph is captured BEFORE the process group exists: RCCL's proxy / watchdog threads touch the HIP runtime on
+    # their own and must never meet an open capture; replay afterwards is an ordinary launch.
     graphed = None
-    # (multi-rank runs stay eager: RCCL's watchdog thread may touch the HIP runtime while a capture is open, and the
-    #  step is GPU-bound either way -- replay only frees the host)
-    if args.graph == "on" and args.inflight == 1 and args.streams == 1 and world == 1:
-        from transformer_explainability_amd.generators import GraphedLRP
+    if args.graph == "on" and args.inflight == 1 and args.streams == 1:
         try:
-            graphed = GraphedLRP(lrp, x, method="transformer_attribution", start_layer=args.start_layer)
+            graphed = GraphedCall(wl.eager, wl.inputs)
             log("HIP graph of one step captured")
         except Exception as exc:      # capture is an optimisation of the host side only: fall back to eager launches
             graphed = None
             torch.cuda.synchronize()
             log(f"HIP graph capture failed ({type(exc).__name__}: {exc}); running eagerly")
 
+    if world > 1:
+        r, w, _ = parallel.init_distributed()
+        assert (r, w) == (rank, world), (r, w, rank, world)
+        log(f"rank {rank}: process group up ({torch.distributed.get_backend()})")
+
     def step(eager=False):
         if graphed is not None and not eager:
-            return graphed(x)
-        if eager and lrp.overlap_backward:
-            # the probe step times single launches with HIP events: run it serially so that a kernel's duration is
-            # its own (with the overlap, kernels of the two streams share the CUs)
-            lrp.overlap_backward = False
-            try:
-                return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
-            finally:
-                lrp.overlap_backward = True
+            return graphed(*wl.inputs)
+        if eager:
+            return wl.eager_serial(*wl.inputs)
         if lanes is None:
-            return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
+            return wl.eager(*wl.inputs)
         # every tensor of a step is allocated, produced and consumed on that step's stream
         lane = lanes[counter[0] % len(lanes)]
         counter[0] += 1
         lane.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(lane):
-            return lrp.generate_LRP(x, method="transformer_attribution", start_layer=args.start_layer)
+            return wl.eager(*wl.inputs)
 
     def join():
         if lanes is not None:
             for lane in lanes:
                 torch.cuda.current_stream(dev).wait_stream(lane)
 
-    for w in range(args.warmup):
+    for w_ in range(args.warmup):
         maps = step()
         torch.cuda.synchronize()
-        log(f"warmup step {w} done")
+        log(f"warmup step {w_} done")
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        # with graph replay, ONE step of the timed region runs eagerly with a HIP-event pair around every launch of
-        # the Linear.relprop kernels (events cannot be recorded inside a replayed graph); the kernels and their
-        # durations are the same in both modes (single stream, back to back)
+        # with graph replay, ONE step of the timed region runs eagerly with a HIP-event pair around every C-ABI call of
+        # the relprop path (events cannot be recorded inside a replayed graph); same kernels, same order, one stream
         probe = (graphed is None) or (k == args.steps - 1)
         timer.enabled = probe and not args.no_roofline
         maps = step(eager=probe and graphed is not None and not args.no_roofline)
@@ -282,24 +536,29 @@ def main():
     ops.KERNEL_TIMER = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if torch.distributed.get_backend() == "gloo":
+            t = t.cpu()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert gathered.shape == (world * B, 196) and torch.isfinite(gathered).all()
+    assert gathered.shape == (world * B, wl.out_cols) and torch.isfinite(gathered).all()
 
     if rank == 0:
         value = world * B * args.steps / elapsed
+        idx = CONFIGS[args.config][0]
         line = {
-            "metric": f"relevance maps/sec (ViT-B/16 224^2, batch {B} per GPU, generate_LRP transformer_attribution)",
-            "value": value, "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": f"relevance {wl.noun}/sec ({wl.title}, batch {B} per GPU, generate_LRP transformer_attribution)",
+            "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ViT-B/16 224^2 batch {B} per GPU on {world}xMI355X: stock fwd + attn-grad bwd + fp32 "
-                                   "relprop/head-mean/rollout HIP kernels (BASELINE.json configs[1], sharded by sample)",
-                       "batch_per_gpu": B, "global_batch": world * B, "tokens": 197, "blocks": 12,
-                       "start_layer": args.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
+            "config": {"workload": f"{wl.title} batch {B} per GPU on {world}xMI355X: stock fwd + attn-grad bwd + fp32 "
+                                   f"relprop/head-mean/rollout HIP kernels (BASELINE.json configs[{idx}], sharded by "
+                                   f"sample)",
+                       "batch_per_gpu": B, "global_batch": world * B, "tokens": wl.tokens, "blocks": wl.blocks,
+                       "start_layer": wl.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "streams": args.streams, "steps_in_flight": args.inflight,
                        "relprop_beside_backward": args.overlap_backward == "on",
                        "blocks_below_start_layer_pruned": args.prune == "on",
+                       "producers": args.producers,
                        "stock_gemm_selection": ("PyTorch TunableOp, committed results file" if tuned and
                                                 args.tuned_gemms == "on" else
                                                 "PyTorch TunableOp, tuned in this run" if tuned else "PyTorch default"),
@@ -308,13 +567,19 @@ def main():
         }
         roof = None
         traffic = None
+        traffic_src = None
         try:   # HBM-side bytes per C-pass launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
-               # MI355X guide's gfx950 correction); only valid for the B = 64 workload they were collected on
-            if B == 64:
-                with open(os.path.join(ROOT, "profiles", "r01_linear_traffic_pmc.json")) as f:
-                    tr = json.load(f)
-                cps = [v["traffic_bytes"] for k, v in tr.items() if k.endswith(".cpass")]
-                traffic = sum(cps) / len(cps)
+               # MI355X guide's gfx950 correction); only valid for the workload they were collected on
+            if args.config == "vit_b16_224" and B == 64:
+                for cand in ("r02_linear_traffic_pmc.json", "r01_linear_traffic_pmc.json"):
+                    path = os.path.join(ROOT, "profiles", cand)
+                    if os.path.exists(path):
+                        with open(path) as f:
+                            tr = json.load(f)
+                        cps = [v["traffic_bytes"] for k, v in tr.items() if k.endswith(".cpass")]
+                        traffic = sum(cps) / len(cps)
+                        traffic_src = cand
+                        break
         except (OSError, ValueError, KeyError):
             traffic = None
         cp = timer.summary("linear_cpass")
@@ -323,16 +588,22 @@ def main():
             roof = {"bound": "mfma", "kernel": "linear_k2_kernel<0,false,false> (Linear.relprop C-pass)",
                     "achieved": cp["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": cp["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": "bytes per launch, mean of the 4 C-pass shapes of a block; offline rocprofv3 --pmc "
-                                    "FETCH_SIZE / WRITE_SIZE passes (profiles/r01_linear_traffic_pmc.json)",
+                    "traffic_note": (f"bytes per launch, mean of the 4 C-pass shapes of a block; offline rocprofv3 --pmc "
+                                     f"FETCH_SIZE / WRITE_SIZE passes (profiles/{traffic_src})") if traffic else None,
                     "launches_timed": cp["launches"], "avg_launch_us": cp["avg_us"],
-                    "algorithmic_flops_per_launch_avg": cp["flops_per_launch_avg"],
+                    "algorithmic_flops_per_launch_avg": cp["flops_per_launch"],
                     "zpass": {"kernel": "linear_k1_kernel<ZM_FWD> (Z-pass from the forward output, 2*T*in*out FLOP)",
-                              "achieved": zp["tflops"], "avg_launch_us": zp["avg_us"]} if zp else None}
+                              "achieved": zp["tflops"], "avg_launch_us": zp["avg_us"]} if zp else None,
+                    "kernels": kernel_table(timer),
+                    "kernels_note": "one eager step inside the timed region; per C-ABI call: HIP events on the launch "
+                                    "stream, ALGORITHMIC flops / bytes (SURVEY.md 8d, App. B), frac = max(flops / "
+                                    f"{MFMA_F32_PEAK_TFLOPS} TF, bytes / {HBM_PEAK_TBS} TB/s) / measured time; launches "
+                                    "carrying < half of the group's largest work (class-token path of the last block) "
+                                    "are excluded from the averages"}
         line["roofline"] = roof
         base = None
         if world == 1 and args.cpu_baseline != "off":
-            base = cpu_baseline(args, cpu_state)
+            base = cpu_baseline(args, wl)
         line["cpu_baseline"] = base
         print(json.dumps(line), flush=True)
     faulthandler.cancel_dump_traceback_later()

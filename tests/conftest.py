@@ -89,6 +89,11 @@ def golden_bert_base():
 
 
 @pytest.fixture(scope="session")
+def golden_bands():
+    return load_golden("bands.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_methods():
     return load_golden("methods.npz")
 

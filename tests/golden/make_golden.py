@@ -237,18 +237,25 @@ def _dist(a, b):
 
 def _band(run32, run64, threads):
     """run32() / run64(): the reference's map of one sample in fp32 / fp64.  Returns (map32 with all threads,
-    band_norm, band_rel) where band = max over {1 thread vs all threads, fp32 vs fp64}."""
+    band_norm, band_rel, ...) where band = max over {1 / 2 / 3 / 4 / 6 threads vs all threads (other GEMM blockings =
+    summation orders), fp32 vs fp64}: six draws of the reference's own rounding noise on this sample."""
     torch.set_num_threads(threads)
     m_all = run32()
-    torch.set_num_threads(1)
-    m_one = run32()
+    d1 = (0.0, 0.0)
+    for t in (1, 2, 3, 4, 6):
+        if t >= threads:
+            continue
+        torch.set_num_threads(t)
+        d = _dist(run32(), m_all)
+        d1 = (max(d1[0], d[0]), max(d1[1], d[1]))
     torch.set_num_threads(threads)
-    m_64 = run64()
-    d1, d2 = _dist(m_one, m_all), _dist(m_all, m_64)
+    d2 = _dist(m_all, run64())
     return m_all, max(d1[0], d2[0]), max(d1[1], d2[1]), d1, d2
 
 
-VIT_BAND_SAMPLES = [(1, 0), (1, 1), (7, 0), (7, 1), (2, 1)]      # (input seed, image index); seed 1 = vit_b16.npz
+# (tag, shape seed-ed, seed, image indices): seed1 = the images of vit_b16.npz; seed7x4 = the batch of
+# test_vit_b16_batch_equals_singles; seed2 = one more well-conditioned sample
+VIT_BAND_SAMPLES = [("seed1", 2, 1, (0, 1)), ("seed7x4", 4, 7, (0, 1, 2, 3)), ("seed2", 2, 2, (1,))]
 
 
 def make_bands():
@@ -260,13 +267,15 @@ def make_bands():
     rh.synthetic_init(model, 0)
     m64 = copy.deepcopy(model).double()
     g32, g64 = vit["gen"].LRP(model), vit["gen"].LRP(m64)
-    for seed, i in VIT_BAND_SAMPLES:
-        x = rh.seeded_randn((2, 3, 224, 224), seed)[i:i + 1]
+    for tag, nimg, seed, idxs in VIT_BAND_SAMPLES:
+      xs = rh.seeded_randn((nimg, 3, 224, 224), seed)
+      for i in idxs:
+        x = xs[i:i + 1]
         for sl in (0, 1):
             r32 = lambda: g32.generate_LRP(x, method="transformer_attribution", start_layer=sl).detach().clone()   # noqa: E731
             r64 = lambda: g64.generate_LRP(x.double(), method="transformer_attribution", start_layer=sl).detach().clone()  # noqa: E731
             m, bn, br, d1, d2 = _band(r32, r64, threads)
-            key = f"vit_b16.seed{seed}.img{i}.sl{sl}"
+            key = f"vit_b16.{tag}.img{i}.sl{sl}"
             out[key + ".map"] = npy(m)
             out[key + ".band_norm"] = np.float64(bn)
             out[key + ".band_rel"] = np.float64(br)

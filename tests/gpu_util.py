@@ -50,21 +50,29 @@ def check_nan_aware(name, got, ref, rel_tol):
     return check(name, torch.nan_to_num(got), torch.nan_to_num(ref), rel_tol)
 
 
-def check_conditioned(name, got, ref32, ref64, base_tol, k=20.0):
-    """Conditioning-aware comparison for rules that divide by a mixed-sign sum (safe_divide(R, Z) with
-    Z = sum of products of either sign): the fp32 oracle itself is only accurate to its own distance
-    from the fp64 oracle on such inputs, so the bar for the HIP result is
-        max|got - ref64| <= k * max|ref32 - ref64| + base_tol * max|ref64|
-    i.e. "as accurate as a plain fp32 evaluation in a different summation order"."""
+def check_conditioned(name, got, ref32, ref64, base_tol, k=3.0, k_max=16.0, q=0.999):
+    """Conditioning-aware comparison for rules that divide by a mixed-sign sum the kernel RECOMPUTES in its own
+    summation order (safe_divide(R, Z), Z = sum of products of either sign; not the model path, which hands the cached
+    forward Z to the rule): the fp32 oracle itself is only as accurate as its distance from the fp64 oracle there.
+
+      * bulk:  the q-quantile (99.9 %) of |got - ref64| <= k x the q-quantile of |ref32 - ref64| + base_tol x max|ref64|
+               with k = 3 -- "as accurate as a plain fp32 evaluation in another summation order";
+      * tail:  max|got - ref64| <= k_max x max|ref32 - ref64| + base_tol x max|ref64|.  The maxima are single draws
+               from a heavy tail (the element with the smallest |Z| of the tensor, error ~ eps |terms| / Z^2), whose
+               ratio reached 11.9 over the 112 recorded cases of round 1 -- hence k_max = 16, not 3."""
     got = got.detach().cpu().double()
     ref32, ref64 = ref32.detach().cpu().double(), ref64.detach().cpu().double()
-    err = float((got - ref64).abs().max())
-    floor = float((ref32 - ref64).abs().max())
+    e_got, e_ref = (got - ref64).abs().flatten(), (ref32 - ref64).abs().flatten()
+    err, floor = float(e_got.max()), float(e_ref.max())
+    kth = max(1, int(q * e_got.numel()))
+    err_q, floor_q = float(e_got.kthvalue(kth).values), float(e_ref.kthvalue(kth).values)
     mx = float(ref64.abs().max())
-    tol = k * floor + base_tol * mx
-    record(name, max_abs_vs_fp64=err, oracle32_vs_fp64=floor, ref_max=mx, rel=err / max(mx, 1e-30), tol_abs=tol,
-           nonfinite=int((~torch.isfinite(got)).sum()))
+    tol = k_max * floor + base_tol * mx
+    tol_q = k * floor_q + base_tol * mx
+    record(name, max_abs_vs_fp64=err, oracle32_vs_fp64=floor, q_abs_vs_fp64=err_q, q_oracle32_vs_fp64=floor_q,
+           ref_max=mx, rel=err / max(mx, 1e-30), tol_abs=tol, tol_q=tol_q, nonfinite=int((~torch.isfinite(got)).sum()))
     assert torch.isfinite(got).all(), name
+    assert err_q <= tol_q, (name, dict(err_q=err_q, floor_q=floor_q, ref_max=mx, tol_q=tol_q))
     assert err <= tol, (name, dict(err=err, floor=floor, ref_max=mx, tol=tol))
 
 

@@ -20,10 +20,33 @@ NORM_TOL = 1e-3         # min-max-normalised map, same cached inputs
 REL_TOL = 2e-3
 # Comparisons across DIFFERENT producers (GPU rocBLAS forward/backward, or a CPU forward on another host, vs the
 # build container's CPU that made tests/golden/*): LRP divides by near-zero mixed-sign sums, so rounding-level
-# producer differences are amplified chaotically on random-init models -- tests/diagnostics/sensitivity_probe.py shows
-# 1-ulp noise on the cached producer tensors moving the oracle's own ViT-B map by up to O(1) relative
-# (DESIGN.md section 4).  Those comparisons therefore assert only the raw north-star bar and RECORD the rest.
-LOOSE = dict(norm_tol=float("inf"), rel_tol=float("inf"))
+# producer differences are amplified chaotically on random-init models.  How much, PER SAMPLE, is measured on the
+# reference itself and committed as tests/golden/bands.npz (make_golden.py bands): the distance of the reference's map
+# from itself when only fp32 rounding changes (1 / 2 / 3 / 4 / 6 threads vs all threads; fp32 vs an fp64 run).  A
+# cross-producer comparison must stay within BAND_K x that band (+ a floor for samples whose band is at rounding level);
+# on the samples picked for a small band this is the north star's 1e-4 on the min-max-normalised map, literally.
+BAND_K = 5.0
+BAND_FLOOR_NORM = 2e-5      # same-cache HIP-vs-oracle distance (2e-7..2e-6) plus head-room; << 1e-4
+BAND_FLOOR_REL = 5e-5
+
+
+def _assert_within_band(name, got, ref, bands, keys, literal_1e4=False):
+    """got / ref [n, M]; keys[i] = the bands.npz key of sample i.  Per sample: normalised and relative distance
+    <= BAND_K x the reference's own noise band on that sample (+ floor); raw north-star bar always."""
+    worst = {}
+    for i, key in enumerate(keys):
+        s = map_stats(got[i:i + 1], ref[i:i + 1])
+        bn, br = bands[key + ".band_norm"], bands[key + ".band_rel"]
+        tol_n, tol_r = BAND_K * bn + BAND_FLOOR_NORM, BAND_K * br + BAND_FLOOR_REL
+        if literal_1e4:
+            tol_n = min(tol_n, 1e-4)
+        record(f"{name}[{i}]", **s, band_norm=bn, band_rel=br, tol_norm=tol_n, tol_rel=tol_r, band_key=key)
+        assert torch.isfinite(got[i]).all()
+        assert s["raw_max_abs"] <= RAW_TOL, (name, i, s)
+        assert s["normalised_max_abs"] <= tol_n, (name, i, s, dict(band_norm=bn, tol=tol_n))
+        assert s["rel_linf"] <= tol_r, (name, i, s, dict(band_rel=br, tol=tol_r))
+        worst[key] = s
+    return worst
 
 
 def _state(g, prefix="state."):
@@ -231,7 +254,7 @@ def test_bert_tiny_golden(golden_bert_tiny):
     assert abs(float(cam.double().sum()) - 1.0) < 1e-4
 
 
-def test_bert_base_pruned_default_start_layer(golden_bert_base):
+def test_bert_base_pruned_default_start_layer(golden_bert_base, golden_bands):
     """Generator(prune=True) at the reference's default start_layer = 11: only the last layer's rules run; same vector."""
     from transformer_explainability_amd import bert
     from transformer_explainability_amd.generators import Generator
@@ -243,8 +266,8 @@ def test_bert_base_pruned_default_start_layer(golden_bert_base):
     for sl in (11, 0):
         full = Generator(model).generate_LRP(ids, mask, start_layer=sl).clone()
         assert torch.equal(Generator(model, prune=True).generate_LRP(ids, mask, start_layer=sl), full)
-    _assert_map("bert_base.pruned_sl11.golden", Generator(model, prune=True).generate_LRP(ids, mask), g["map_sl11"],
-                **LOOSE)
+    _assert_within_band("bert_base.pruned_sl11.golden", Generator(model, prune=True).generate_LRP(ids, mask),
+                        g["map_sl11"], golden_bands, ["bert_base.map_sl11"], literal_1e4=True)
 
 
 def test_bert_tiny_other_methods(golden_bert_tiny, golden_methods):
@@ -268,7 +291,7 @@ def test_bert_tiny_other_methods(golden_bert_tiny, golden_methods):
     check_nan_aware("bert_tiny.attn_gradcam", gen.generate_attn_gradcam(ids, mask), gm["bert.attn_gradcam"], 1e-3)
 
 
-def test_tuned_stock_gemms(vit_b16):
+def test_tuned_stock_gemms(vit_b16, golden_bands):
     """enable_tuned_gemms() only changes which stock fp32 GEMM kernels forward / backward run: the maps stay within the
     cross-producer band of the default kernels, and HIP relprop == oracle on the tensors that forward produced."""
     import torch.cuda.tunable as tunable
@@ -287,7 +310,8 @@ def test_tuned_stock_gemms(vit_b16):
     finally:
         tunable.enable(False)
     _assert_map("vit_b16.tuned_gemms.same_cache_oracle", tuned, ref)
-    _assert_map("vit_b16.tuned_vs_default_gemms", tuned, base, **LOOSE)
+    _assert_within_band("vit_b16.tuned_vs_default_gemms", tuned, base, golden_bands,
+                        [f"vit_b16.seed1.img{i}.sl1" for i in range(2)])
 
 
 # ------------------------------------------------------------------------------------------ ViT-B/16 full size
@@ -305,10 +329,10 @@ def _one_hot_of(logits):
     return oh
 
 
-def test_vit_b16_hip_relprop_on_cpu_producers(vit_b16, golden_vit_b16):
+def test_vit_b16_hip_relprop_on_cpu_producers(vit_b16, golden_vit_b16, golden_bands):
     """Producers on the CPU (stock ATen CPU forward + attention-gradient backward, as in the reference), cached
     tensors moved to the MI355X, ONLY relprop / head-mean / rollout as HIP kernels.  Checked (tight) against the
-    oracle on the same cached tensors and (raw bar; see LOOSE) against the reference's golden maps, which came
+    oracle on the same cached tensors and (within the reference's own noise band on that sample: _assert_within_band) against the reference's golden maps, which came
     from another host's CPU."""
     from gpu_util import move_relprop_state
     from transformer_explainability_amd.generators import _attention_gradients
@@ -327,11 +351,12 @@ def test_vit_b16_hip_relprop_on_cpu_producers(vit_b16, golden_vit_b16):
             got = model.relprop(oh.to(dev()), method="transformer_attribution", start_layer=sl, alpha=1)
             ref = O.vit_relprop(oh, cache, num_heads=12, start_layer=sl)
             _assert_map(f"vit_b16.cpu_producers.oracle.map_sl{sl}.{i}", got, ref["map"], norm_tol=2e-4, rel_tol=3e-4)
-            _assert_map(f"vit_b16.cpu_producers.golden.map_sl{sl}.{i}", got, g[f"map_sl{sl}"][i:i + 1], **LOOSE)
+            _assert_within_band(f"vit_b16.cpu_producers.golden.map_sl{sl}.{i}", got, g[f"map_sl{sl}"][i:i + 1],
+                                golden_bands, [f"vit_b16.seed1.img{i}.sl{sl}"])
     model.to("cpu")
 
 
-def test_vit_b16_golden_and_oracle(vit_b16, golden_vit_b16):
+def test_vit_b16_golden_and_oracle(vit_b16, golden_vit_b16, golden_bands):
     """configs[1] of BASELINE.json at parity-test size, producers on the GPU: 2 seeded 224^2 images.
     (a) HIP relprop vs the oracle evaluated on the very tensors our GPU forward/backward cached -- the
         kernels in isolation, tight;
@@ -357,15 +382,39 @@ def test_vit_b16_golden_and_oracle(vit_b16, golden_vit_b16):
         if sl == 0:
             for i in (0, 5, 11):
                 check(f"vit_b16.oracle.attn_cam.{i}", model.blocks[i].attn.get_attn_cam(), ref["attn_cams"][i], 1e-3)
-        _assert_map(f"vit_b16.golden.map_sl{sl}", out, g[f"map_sl{sl}"], **LOOSE)
+        _assert_within_band(f"vit_b16.golden.map_sl{sl}", out, g[f"map_sl{sl}"], golden_bands,
+                            [f"vit_b16.seed1.img{i}.sl{sl}" for i in range(2)])
     model.to("cpu")
 
 
-def test_vit_b16_batch_equals_singles(vit_b16):
+def test_vit_b16_north_star_bar_on_benign_samples(vit_b16, golden_bands):
+    """BASELINE.md section 4, literally: on the ViT-B/16 samples whose reference map is well conditioned (the
+    reference's own fp32 noise band on them is <= 5e-5 normalised: bands.npz), the GPU end-to-end map -- rocBLAS
+    forward + backward, HIP relprop -- is within 1e-4 of the reference's CPU map after min-max normalisation (what
+    imagenet_seg_eval.py:217 consumes), and within 1e-4 raw."""
+    from transformer_explainability_amd.generators import LRP
+    b = golden_bands
+    model = vit_b16.to(dev())
+    lrp = LRP(model)
+    picked = [(tag, nimg, seed, i) for tag, nimg, seed, idxs in (("seed1", 2, 1, (0, 1)), ("seed7x4", 4, 7, (0, 1, 2, 3)),
+                                                                 ("seed2", 2, 2, (1,)))
+              for i in idxs if b[f"vit_b16.{tag}.img{i}.sl0.band_norm"] <= 5e-5]
+    assert len(picked) >= 2, "bands.npz holds too few well-conditioned samples"
+    for tag, nimg, seed, i in picked:
+        x = seeded_randn((nimg, 3, 224, 224), seed)[i:i + 1].to(dev())
+        out = lrp.generate_LRP(x, method="transformer_attribution", start_layer=0)
+        key = f"vit_b16.{tag}.img{i}.sl0"
+        s = map_stats(out, b[key + ".map"])
+        record(f"vit_b16.north_star.{tag}.img{i}", **s, band_norm=b[key + ".band_norm"])
+        assert s["raw_max_abs"] <= 1e-4 and s["normalised_max_abs"] <= 1e-4, (key, s)
+    model.to("cpu")
+
+
+def test_vit_b16_batch_equals_singles(vit_b16, golden_bands):
     """Batch = independent samples.  One batched forward/backward (B = 4); relprop on the whole batch must equal
     -- BITWISE -- relprop on each sample's slice of the very same cached tensors (no kernel couples samples or
     depends on which rows share a tile).  Against B separate forward passes only the raw bar is asserted: rocBLAS
-    picks different tilings for M = 197 and M = 788 and LRP amplifies that (see LOOSE)."""
+    picks different tilings for M = 197 and M = 788 and LRP amplifies that (bounded by the per-sample band: _assert_within_band)."""
     from gpu_util import sliced_relprop_state
     from transformer_explainability_amd.generators import LRP
     model = vit_b16.to(dev())
@@ -403,7 +452,8 @@ def test_vit_b16_batch_equals_singles(vit_b16):
         recomputed = model.relprop(oh, method="transformer_attribution", start_layer=1, alpha=1)
     finally:
         _ops.USE_FORWARD_PRODUCTS = True
-    _assert_map("vit_b16.attention_forwardZ_vs_recomputedZ", batch, recomputed, **LOOSE)
+    band_keys = [f"vit_b16.seed7x4.img{i}.sl1" for i in range(B)]
+    _assert_within_band("vit_b16.attention_forwardZ_vs_recomputedZ", batch, recomputed, golden_bands, band_keys)
     # micro-batches on separate HIP streams == the same micro-batches run one after the other, bitwise
     streamed = LRP(model, streams=2).generate_LRP(x, start_layer=1)
     halves = torch.cat([lrp.generate_LRP(x[:2], start_layer=1), lrp.generate_LRP(x[2:], start_layer=1)], 0)
@@ -429,7 +479,10 @@ def test_vit_b16_batch_equals_singles(vit_b16):
     assert torch.equal(LRP(model, prune=True, overlap_backward=True).generate_LRP(x2, start_layer=1), replayed)
     model.prune_below_start_layer = False
     singles = torch.cat([lrp.generate_LRP(x[i:i + 1], start_layer=1) for i in range(B)], 0)
-    _assert_map("vit_b16.batch_vs_separate_forwards", batch, singles, **LOOSE)
+    _assert_within_band("vit_b16.batch_vs_separate_forwards", batch, singles, golden_bands, band_keys)
+    # ... and each against the reference's own map of that image
+    _assert_within_band("vit_b16.seed7x4.golden.map_sl1", batch,
+                        torch.cat([golden_bands[k + ".map"] for k in band_keys], 0), golden_bands, band_keys)
     # LRP conservation: the token relevance of every sample sums to 1
     logits = model(x)
     oh = _one_hot_of(logits.detach())
@@ -456,9 +509,9 @@ def _bert_base(g):
     return model
 
 
-def test_bert_base_hip_relprop_on_cpu_producers(golden_bert_base):
+def test_bert_base_hip_relprop_on_cpu_producers(golden_bert_base, golden_bands):
     """BERT-base (padded sequence): CPU forward + backward, HIP relprop / head-mean / rollout on the moved caches,
-    vs the oracle on the same caches (tight) and the reference's golden output (raw bar; see LOOSE)."""
+    vs the oracle on the same caches (tight) and the reference's golden output (within the reference's own noise band on that sample: _assert_within_band)."""
     from gpu_util import move_relprop_state
     from transformer_explainability_amd.generators import Generator, _attention_gradients
     g = golden_bert_base
@@ -477,12 +530,13 @@ def test_bert_base_hip_relprop_on_cpu_producers(golden_bert_base):
             got = gen.attribution_tail(start_layer=sl)
             ref = O.bert_relprop(oh, cache, num_heads=12, start_layer=sl)
             _assert_map(f"bert_base.cpu_producers.oracle.map_{tag}sl{sl}", got, ref["map"], norm_tol=2e-4, rel_tol=3e-4)
-            _assert_map(f"bert_base.cpu_producers.golden.map_{tag}sl{sl}", got, g[f"map_{tag}sl{sl}"], **LOOSE)
+            _assert_within_band(f"bert_base.cpu_producers.golden.map_{tag}sl{sl}", got, g[f"map_{tag}sl{sl}"],
+                                golden_bands, [f"bert_base.map_{tag}sl{sl}"], literal_1e4=(sl == 11))
 
 
-def test_bert_base_golden_and_oracle(golden_bert_base):
+def test_bert_base_golden_and_oracle(golden_bert_base, golden_bands):
     """Producers on the GPU: (a) HIP vs oracle on our cached tensors (tight); (b) end to end vs the reference's
-    CPU output: raw north-star bar, rest recorded (see LOOSE)."""
+    CPU output: within the reference's own per-sample noise band (_assert_within_band)."""
     from transformer_explainability_amd.generators import Generator
     g = golden_bert_base
     model = _bert_base(g).to(dev())
@@ -494,7 +548,8 @@ def test_bert_base_golden_and_oracle(golden_bert_base):
         oh = _one_hot_of(model.classifier.Y.detach().float().cpu())
         ref = O.bert_relprop(oh, cache, num_heads=12, start_layer=sl)
         _assert_map(f"bert_base.oracle.map_sl{sl}", out, ref["map"], norm_tol=2e-4, rel_tol=3e-4)
-        _assert_map(f"bert_base.golden.map_sl{sl}", out, g[f"map_sl{sl}"], **LOOSE)
+        _assert_within_band(f"bert_base.golden.map_sl{sl}", out, g[f"map_sl{sl}"], golden_bands,
+                            [f"bert_base.map_sl{sl}"], literal_1e4=(sl == 11))
     # exact token-0 sparsity shortcut of the last layer (bert.BertLayer.relprop_cls_only) == dense evaluation
     oh_d = _one_hot_of(model.classifier.Y.detach())
     sparse_cam = model.relprop(oh_d, alpha=1)
@@ -506,7 +561,7 @@ def test_bert_base_golden_and_oracle(golden_bert_base):
     for l, lay in enumerate(model.bert.encoder.layer):
         assert torch.equal(lay.attention.self.get_attn_cam(), sparse_cams[l]), l
     out = gen.generate_LRP(input_ids=ids, attention_mask=torch.ones_like(mask), start_layer=0)
-    _assert_map("bert_base.golden.nomask", out, g["map_nomask_sl0"], **LOOSE)
+    _assert_within_band("bert_base.golden.nomask", out, g["map_nomask_sl0"], golden_bands, ["bert_base.map_nomask_sl0"])
 
 
 # ------------------------------------------------------------------------------------------ full-size configs

@@ -310,6 +310,98 @@ def test_rollout(L, B, N, start, normalise, simple):
     check(f"rollout_fixup({L},{B},{N},{start},{normalise})", got2, ref2, 1e-5)
 
 
+@pytest.mark.parametrize("L,B,N,start", [(4, 2, 50, 0), (12, 2, 197, 1), (3, 1, 197, 2), (5, 3, 64, 4), (4, 2, 577, 1),
+                                         (3, 2, 512, 0), (3, 1, 1, 0), (12, 64, 197, 1), (2, 1, 1024, 0)])
+@pytest.mark.parametrize("normalise", [False, True])
+def test_rollout_row0_chain(L, B, N, start, normalise):
+    """TE_ROLLOUT_ROW0: row 0 of the chain product as a vector x matrix chain (what both generators consume) vs the
+    oracle's full product chain, with and without the CLS fix-up; a batch equals its samples run alone, bitwise."""
+    from transformer_explainability_amd import ops
+    cams = rnd((L, B, N, N), 43).abs() * 0.01
+    ref = O.rollout(list(cams), start, normalise=normalise)
+    got = ops.rollout(cams.to(dev()), start_layer=start, normalise=normalise, row0_only=True)
+    assert got.shape == (B, N)
+    check(f"rollout_row0({L},{B},{N},{start},{normalise})", got, ref[:, 0], 1e-5)
+    got2 = ops.rollout(cams.to(dev()), start_layer=start, normalise=normalise, cls_fixup=True, row0_only=True)
+    ref2 = ref[:, 0].clone()
+    ref2[:, 0] = ref[:, 0].min(dim=-1).values
+    check(f"rollout_row0_fixup({L},{B},{N},{start},{normalise})", got2, ref2, 1e-5)
+    # the full-matrix path sliced afterwards (flag off) agrees to rounding
+    ops.USE_ROW0_CHAIN = False
+    try:
+        full = ops.rollout(cams.to(dev()), start_layer=start, normalise=normalise, row0_only=True)
+    finally:
+        ops.USE_ROW0_CHAIN = True
+    check(f"rollout_row0_vs_matrix({L},{B},{N},{start},{normalise})", got, full, 1e-5)
+    if B > 1:
+        for i in (0, B - 1):
+            one = ops.rollout(cams[:, i:i + 1].contiguous().to(dev()), start_layer=start, normalise=normalise,
+                              row0_only=True)
+            assert torch.equal(one[0], got[i]), (i, float((one[0] - got[i]).abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ deferred Add factor
+@pytest.mark.parametrize("shape", [(1, 9, 16), (3, 197, 768), (2, 5, 3), (64, 33, 64), (5, 1, 768)])
+def test_add_deferred_equals_two_pass(shape):
+    """te_add_relprop_deferred_f32 (one streaming pass, per-sample factor handed to the consumers) == the two-pass rule,
+    BITWISE, once the factor is applied; and the consumers applying it in-kernel (Clone, Linear Z-pass epilogue) ==
+    the same consumers fed the materialised tensors, bitwise."""
+    from transformer_explainability_amd import ops
+    X0, X1, R = rnd(shape, 2), rnd(shape, 3), rnd(shape, 4, 0.01)
+    X0.view(-1)[0] = 0.0
+    X1.view(-1)[0] = 0.0
+    d = dev()
+    a, b = ops.add_relprop(R.to(d), X0.to(d), X1.to(d), variant="ours")
+    da, db = ops.add_relprop(R.to(d), X0.to(d), X1.to(d), variant="ours", deferred=True)
+    assert isinstance(da, ops.Deferred) and isinstance(db, ops.Deferred)
+    assert torch.equal(da.materialise(), a), float((da.materialise() - a).abs().max())
+    assert torch.equal(db.materialise(), b), float((db.materialise() - b).abs().max())
+    ra, rb = O.add_relprop(R, X0, X1, "ours")
+    check(f"add_deferred{shape}.a", da.materialise(), ra, 2e-5)
+    check(f"add_deferred{shape}.b", db.materialise(), rb, 2e-5)
+    # Clone consuming (deferred, plain) / (deferred, deferred, plain)
+    Xc = rnd(shape, 5).to(d)
+    other = rnd(shape, 6, 0.01).to(d)
+    assert torch.equal(ops.clone_relprop((da, other), Xc), ops.clone_relprop((a, other), Xc))
+    assert torch.equal(ops.clone_relprop((other, db, da), Xc), ops.clone_relprop((other, b, a), Xc))
+    # lrp variant has no rescale: the flag is ignored
+    la, lb = ops.add_relprop(R.to(d), X0.to(d), X1.to(d), variant="lrp", deferred=True)
+    assert torch.is_tensor(la) and torch.is_tensor(lb)
+
+
+@pytest.mark.parametrize("B,N,in_f,out_f", [(3, 197, 768, 768), (2, 197, 3072, 768), (64, 1, 768, 768), (2, 50, 64, 192),
+                                            (5, 33, 24, 40)])
+def test_linear_with_deferred_relevance(B, N, in_f, out_f):
+    """Linear.relprop whose relevance operand carries a deferred per-sample factor (row t scaled by s[t // N] inside
+    the Z-pass epilogue) == the rule on the materialised operand, bitwise -- interior and edge tiles, rows of one
+    32-row accumulator block spanning two samples (N = 197, 50, 33) and N = 1 (class-token path)."""
+    from transformer_explainability_amd import ops
+    d = dev()
+    X, W, bias = rnd((B, N, in_f), 61).to(d), (rnd((out_f, in_f), 62) * 0.05).to(d), (rnd((out_f,), 63) * 0.1).to(d)
+    Y = torch.nn.functional.linear(X, W, bias)
+    R = rnd((B, N, out_f), 64, 0.01).to(d)
+    fac = (rnd((B, 2), 65).abs() + 0.5).to(d)
+    Rd = ops.Deferred(R, fac[:, 1])
+    got = ops.linear_relprop(Rd, X, W, Y=Y, bias=bias)
+    ref = ops.linear_relprop(Rd.materialise(), X, W, Y=Y, bias=bias)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    # no cached forward output: the operand is materialised on the host side
+    got2 = ops.linear_relprop(Rd, X, W)
+    ref2 = ops.linear_relprop(Rd.materialise(), X, W)
+    assert torch.equal(got2, ref2)
+    check(f"linear_deferred({B},{N},{in_f},{out_f})", got, O.linear_relprop(Rd.materialise().cpu(), X.cpu(), W.cpu()), 3e-5)
+
+
+@pytest.mark.parametrize("B,H,N", [(3, 16, 50), (1, 12, 577), (2, 20, 33), (64, 12, 197)])
+def test_headmean_more_shapes(B, H, N):
+    """Head-mean kernel (flat form: every head's loads in flight, H <= 16; grid-stride form beyond) on 16 / 20 heads,
+    N = 577 and the bench shape; heads are added in index order, then divided by H, like torch's mean."""
+    from transformer_explainability_amd import ops
+    g, c = rnd((B, H, N, N), 13), rnd((B, H, N, N), 14, 0.01)
+    got = ops.gradcam_headmean(g.to(dev()), c.to(dev()))
+    check(f"headmean_more({B},{H},{N})", got, O.gradcam_headmean(g, c), 1e-6)
+
+
 # ------------------------------------------------------------------------------------------ golden (reference outputs)
 def test_golden_rules(golden_rules):
     from transformer_explainability_amd import ops

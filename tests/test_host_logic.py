@@ -257,3 +257,47 @@ def test_cpu_only_hosts_get_no_silent_fallback():
     assert te.enable_tuned_gemms() is False
     with pytest.raises(te.TeError):
         ops.clone_relprop((torch.zeros(1, 2, 4), torch.zeros(1, 2, 4)), torch.ones(1, 2, 4))
+
+
+def test_bench_refuses_fewer_gpus_than_ranks():
+    """`python bench.py --gpus 2` on a host with fewer than 2 GPUs must fail loudly -- never print an n_gpus: 1 line."""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("needs a host with < 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TE_DEVICE_OVERRIDE",
+                                                            "TE_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "refusing to run 2 ranks" in r.stderr and '"n_gpus"' not in r.stdout
+    # under a launcher whose world size disagrees with --gpus: also an error, not a silent 1-rank run
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr and '"n_gpus"' not in r.stdout
+
+
+def test_reference_stage_matches_checkout():
+    """oracle/_ref (what travels to the GPU box for the cpu_baseline leg) is a byte-for-byte copy of the reference's
+    hot-path files: MANIFEST checksums hold, and against /root/reference when it is present."""
+    import hashlib
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_stage", os.path.join(root, "scripts", "stage_reference.py"))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    if not os.path.exists(os.path.join(st.DEST, "MANIFEST.json")):
+        if not st.stage(quiet=True):
+            pytest.skip("no reference checkout and no stage on this host")
+    assert st.check()
+    if os.path.isdir("/root/reference/modules"):
+        with open(os.path.join(st.DEST, "MANIFEST.json")) as f:
+            man = json.load(f)["sha256"]
+        for rel, h in man.items():
+            with open(os.path.join("/root/reference", rel), "rb") as f:
+                assert hashlib.sha256(f.read()).hexdigest() == h, rel

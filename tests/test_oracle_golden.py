@@ -126,3 +126,61 @@ def test_vit_tiny_full_tail(golden_vit_tiny, golden_methods):
     cache.update(pos_add_x0=tokens, pos_embed=state["pos_embed"], patch_x=x, patch_w=state["patch_embed.proj.weight"])
     full = O.vit_full_tail(g["ours.cam_tokens"], cache)
     _close(full, golden_methods["ours.full"][:1], rel=1e-5)
+
+
+# ---- live reference (the checkout, or its stage oracle/_ref) vs the oracle on FRESH seeds --------------------------
+def _live_reference():
+    from oracle import ref_harness as rh
+    if not rh.reference_available():
+        pytest.skip("no reference checkout / stage on this host")
+    return rh
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+@pytest.mark.parametrize("variant", ["ours", "lrp"])
+def test_live_reference_vit_vs_oracle(seed, variant):
+    """Runs the unmodified reference NOW (not a replayed fixture) on a freshly seeded small ViT and input, extracts the
+    tensors its relprop reads, and requires the oracle to reproduce every block's attn_cam and the final map."""
+    rh = _live_reference()
+    vit = rh.load_reference_vit()
+    modname, method = (("ViT_LRP", "transformer_attribution") if variant == "ours" else ("ViT_orig_LRP", "grad"))
+    model = vit[modname].VisionTransformer(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=10,
+                                           qkv_bias=True).eval()
+    rh.synthetic_init(model, seed)
+    x = rh.seeded_randn((1, 3, 32, 32), seed + 1)
+    gen = vit["gen"].LRP(model)
+    for sl in (0, 1):
+        ref_map = gen.generate_LRP(x, method=method, start_layer=sl).detach().clone()
+        cache = rh.vit_cache_from_reference(model)
+        logits = model(x)
+        oh = torch.zeros_like(logits)
+        oh[0, logits.argmax(-1)] = 1
+        res = O.vit_relprop(oh, cache, num_heads=4, start_layer=sl, variant=variant)
+        _close(res["map"], ref_map, 1e-5)
+        for i, blk in enumerate(model.blocks):
+            _close(res["attn_cams"][i], blk.attn.get_attn_cam().detach(), 1e-5)
+
+
+@pytest.mark.parametrize("seed", [303])
+def test_live_reference_bert_vs_oracle(seed):
+    rh = _live_reference()
+    bert = rh.load_reference_bert()
+    from transformers import BertConfig
+    cfg = BertConfig(vocab_size=100, hidden_size=64, num_hidden_layers=3, num_attention_heads=4, intermediate_size=128,
+                     max_position_embeddings=40, num_labels=2)
+    cfg.return_dict = False
+    model = bert["cls"].BertForSequenceClassification(cfg).eval()
+    rh.synthetic_init(model, seed)
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, 100, (1, 24), generator=g)
+    mask = torch.ones(1, 24)
+    mask[:, 18:] = 0
+    gen = bert["gen"].Generator(model)
+    for sl in (0, 2):
+        ref_map = gen.generate_LRP(input_ids=ids, attention_mask=mask, start_layer=sl).detach().clone()
+        cache = rh.bert_cache_from_reference(model)
+        logits = model(input_ids=ids, attention_mask=mask)[0]
+        oh = torch.zeros_like(logits)
+        oh[0, logits.argmax(-1)] = 1
+        res = O.bert_relprop(oh, cache, num_heads=4, start_layer=sl)
+        _close(res["map"], ref_map, 1e-5)
