@@ -402,7 +402,8 @@ def cpu_baseline(args, wl):
         times = []
         for i in range(n_maps + 1):
             t0 = time.perf_counter()
-            run(i % n_in)
+            with rh.reference_on_cpu():         # the reference hard-codes .cuda(); this leg runs on the host cores
+                run(i % n_in)
             times.append(time.perf_counter() - t0)
             log(f"cpu_baseline({kind}, {threads} threads) {wl.noun[:-1]} {i}: {times[-1]:.2f} s")
         times = sorted(times[1:])

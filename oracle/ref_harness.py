@@ -81,6 +81,19 @@ def _cuda_identity_shim():
         torch.Tensor.cuda = lambda self, *a, **k: self
 
 
+@contextmanager
+def reference_on_cpu():
+    """Run the reference on the HOST even where a GPU is visible (bench.py's cpu_baseline leg on the GPU box): its
+    generators hard-code ``.cuda()`` (ViT_explanation_generator.py:35, ExplanationGenerator.py:40), which would move
+    the one-hot to the device while the model sits on the CPU.  ``Tensor.cuda`` is the identity inside the block."""
+    saved = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda = saved
+
+
 def load_reference_vit():
     """Returns the reference modules (ViT_LRP, ViT_orig_LRP, generator, layers_ours, layers_lrp)."""
     _cuda_identity_shim()

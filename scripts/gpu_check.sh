@@ -3,7 +3,7 @@
 # the self-launching 2-rank path on the one-GPU rig.
 #   gpurun --timeout 1500 -- 'bash scripts/gpu_check.sh'      (logs land in gpurun_out/)
 mkdir -p gpurun_out; rm -f gpurun_out/parity_report.jsonl; rm -rf gpurun_out/prof; export TMPDIR=/tmp
-( timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=5 -x 2>&1 | tail -40 ) > gpurun_out/tests_full.log
+( timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=5 --maxfail=6 2>&1 | tail -60 ) > gpurun_out/tests_full.log
 ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5 ) > gpurun_out/smoke.log
 ( timeout 400 python bench.py > gpurun_out/bench_b64.json 2> gpurun_out/bench_b64.err )
 ( cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d "$OLDPWD/gpurun_out/prof" -o bench -- \
@@ -11,6 +11,8 @@ mkdir -p gpurun_out; rm -f gpurun_out/parity_report.jsonl; rm -rf gpurun_out/pro
 rm -f gpurun_out/prof/*agent_info* gpurun_out/prof/*kernel_trace*
 ( timeout 200 python scripts/stream_kernels_bw.py 2>&1 | tail -12 ) > gpurun_out/stream_kernels_bw.log
 ( TE_HEADMEAN_VARIANT=0 timeout 100 python scripts/stream_kernels_bw.py --only headmean 2>&1 | tail -3 ) >> gpurun_out/stream_kernels_bw.log
+( for impl in rules tiles; do echo "TE_ATTN_IMPL=$impl"; for shape in "64 12 197" "32 16 577" "32 12 512"; do
+    TE_ATTN_IMPL=$impl timeout 120 python scripts/attn_bench.py $shape 2>&1 | tail -1; done; done ) > gpurun_out/attn_bench.log
 ( TE_DIST_BACKEND=gloo TE_DEVICE_OVERRIDE=0 timeout 300 python bench.py --gpus 2 --batch 16 --steps 2 --warmup 1 \
     > gpurun_out/bench_2rank_rig.json 2> gpurun_out/bench_2rank_rig.err )
 echo "=== tests ==="; cat gpurun_out/tests_full.log
@@ -18,4 +20,5 @@ echo "=== smoke ==="; cat gpurun_out/smoke.log
 echo "=== bench ==="; cat gpurun_out/bench_b64.json; tail -25 gpurun_out/bench_b64.err
 echo "=== rocprof top kernels ==="; head -14 gpurun_out/prof/bench_kernel_stats.csv | cut -d, -f1-4
 echo "=== streaming kernels ==="; cat gpurun_out/stream_kernels_bw.log
-echo "=== 2-rank rig ==="; cat gpurun_out/bench_2rank_rig.json; tail -5 gpurun_out/bench_2rank_rig.err
+echo "=== attention rules ==="; cat gpurun_out/attn_bench.log
+echo "=== 2-rank rig ==="; cut -c1-400 gpurun_out/bench_2rank_rig.json; tail -3 gpurun_out/bench_2rank_rig.err

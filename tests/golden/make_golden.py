@@ -235,10 +235,11 @@ def _dist(a, b):
             float((a - b).abs().max()) / max(float(b.abs().max()), 1e-300))
 
 
-def _band(run32, run64, threads):
+def _band(run32, run64, threads, run32_noisy=None):
     """run32() / run64(): the reference's map of one sample in fp32 / fp64.  Returns (map32 with all threads,
     band_norm, band_rel, ...) where band = max over {1 / 2 / 3 / 4 / 6 threads vs all threads (other GEMM blockings =
-    summation orders), fp32 vs fp64}: six draws of the reference's own rounding noise on this sample."""
+    summation orders), fp32 vs fp64, and (ViT) three draws of 1-ulp noise on the input image}: the reference's own
+    rounding noise on this sample."""
     torch.set_num_threads(threads)
     m_all = run32()
     d1 = (0.0, 0.0)
@@ -250,7 +251,18 @@ def _band(run32, run64, threads):
         d1 = (max(d1[0], d[0]), max(d1[1], d[1]))
     torch.set_num_threads(threads)
     d2 = _dist(m_all, run64())
+    # 1-ulp noise on the INPUT (three draws): fresh rounding noise in every layer, the kind of perturbation another
+    # GEMM summation order or another exp / erf implementation makes (thread counts only re-partition M and N)
+    if run32_noisy is not None:
+        for draw in range(3):
+            d = _dist(run32_noisy(draw), m_all)
+            d1 = (max(d1[0], d[0]), max(d1[1], d[1]))
     return m_all, max(d1[0], d2[0]), max(d1[1], d2[1]), d1, d2
+
+
+def _ulp_noise(x, draw):
+    g = torch.Generator().manual_seed(9000 + draw)
+    return x * (1.0 + 2.0 ** -24 * torch.randn(x.shape, generator=g))
 
 
 # (tag, shape seed-ed, seed, image indices): seed1 = the images of vit_b16.npz; seed7x4 = the batch of
@@ -274,7 +286,9 @@ def make_bands():
         for sl in (0, 1):
             r32 = lambda: g32.generate_LRP(x, method="transformer_attribution", start_layer=sl).detach().clone()   # noqa: E731
             r64 = lambda: g64.generate_LRP(x.double(), method="transformer_attribution", start_layer=sl).detach().clone()  # noqa: E731
-            m, bn, br, d1, d2 = _band(r32, r64, threads)
+            rn = lambda dr: g32.generate_LRP(_ulp_noise(x, dr), method="transformer_attribution",                # noqa: E731
+                                             start_layer=sl).detach().clone()
+            m, bn, br, d1, d2 = _band(r32, r64, threads, rn)
             key = f"vit_b16.{tag}.img{i}.sl{sl}"
             out[key + ".map"] = npy(m)
             out[key + ".band_norm"] = np.float64(bn)

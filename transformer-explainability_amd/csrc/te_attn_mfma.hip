@@ -24,6 +24,18 @@
 // land on one XCD and share that L2's copy of k / v / S.
 #include "te_common.h"
 
+namespace te_attn_rules {   // te_attn_rules.hip: the one-pass rule kernels (default)
+bool enabled();
+bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
+int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn, const float* v, int64_t v_sb,
+              int64_t v_sh, int64_t v_sn, const float* Z, float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh,
+              int64_t cv_sn, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream);
+int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
+              int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
+              float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
+              float* qpart, hipStream_t stream);
+}  // namespace te_attn_rules
+
 namespace te_attn_mfma {
 
 namespace {
@@ -513,6 +525,9 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
     z_av_kernel<<<grid, blk, 0, stream>>>(attn, v, vs, wsZ, (int)H, (int)N, BH);
     Z = wsZ;
   }
+  if (te_attn_rules::enabled() && te_attn_rules::supported(B, H, N, D))
+    return te_attn_rules::av_launch(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, cam_attn, cam_v, cv_sb, cv_sh,
+                                    cv_sn, B, H, N, scale, stream);
   av_row_kernel<<<grid, blk, 0, stream>>>(R, rs, Z, attn, v, vs, cam_attn, wsS, (int)H, (int)N, BH, scale);
   col_kernel<<<grid, blk, 0, stream>>>(attn, wsS, ss, v, vs, cam_v, cs, (int)H, (int)N, BH, scale);
   return TE_OK;
@@ -534,6 +549,11 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
     z_qk_kernel<<<dim3((unsigned)(BH * nt * nt)), blk, 0, stream>>>(q, qs, k, ks, wsZ, (int)H, (int)N, BH, nt);
     Z = wsZ;
   }
+  if (te_attn_rules::enabled() && te_attn_rules::supported(B, H, N, D))
+    // (the per-group cam_q partials of N > 256 live in the S region of the workspace, which this path never writes:
+    //  ngroups * 64 <= N whenever ngroups > 1)
+    return te_attn_rules::qk_launch(Rnn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn, cam_k,
+                                    ck_sb, ck_sh, ck_sn, B, H, N, scale, wsS, stream);
   qk_row_kernel<<<grid, blk, 0, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, wsS, (int)H, (int)N, BH, scale);
   col_kernel<<<grid, blk, 0, stream>>>(wsS, q, qs, k, ks, cam_k, cks, (int)H, (int)N, BH, scale);
   return TE_OK;

@@ -1,0 +1,426 @@
+// te_attn_rules.hip -- ONE-PASS attention relprop rules for gfx950 (head dim 64): each rule reads its N x N operands
+// once and never writes S = safe_divide(R, Z) to memory (modules/layers_ours.py:48-60,122-127; ViT_LRP.py:157-173;
+// BERT.py:367-393).
+//
+//   AV rule:  S = sd(R, Z_av) [N,64];  cam_attn = attn .(S v^T);  cam_v = v .(attn^T S)
+//   QK rule:  S = sd(R_nn, Z_qk) [N,N]; cam_q = q .(S k);         cam_k = k .(S^T q)
+//
+// Z is the cached forward product of the very einsum / MatMul whose rule is evaluated (te_attn_mfma.hip header).
+//
+// One workgroup (512 threads = 8 waves, one per (b, h, key group of <= 256 keys)) keeps the key-side operand (v or k,
+// <= 256 x 64) resident in LDS and walks the query rows in tiles of 32.  Per tile the row-side product AND the
+// column-side product are formed from the same LDS image of the [32, keys] tile:
+//
+//   AV:  S tile [32,64] (from R, Z) and the attn tile [32,keys] -> LDS
+//        G = S v^T            one 32x32 output block per wave (v_mfma_f32_32x32x2_f32), K = 64
+//        cam_attn = attn . G  straight from the accumulators
+//        cam_v  += attn^T S   (keys x 64) as 32x32 blocks, two per wave, accumulators live across all row tiles
+//   QK:  S tile [32,keys] = sd(R_nn, Z_qk) and the q tile [32,64] -> LDS
+//        cam_q  = S k         32x64 output as eight 16x16 blocks, one per wave (v_mfma_f32_16x16x4_f32), K = keys:
+//                             every wave busy without a split-K reduction
+//        cam_k += S^T q       as for cam_v
+//
+// Every tile of the next step is requested (global -> registers) before the MFMAs of the current one start, so HBM
+// latency hides under ~4000 MFMA-pipe cycles per wave and tile.  Traffic per (b,h): AV reads attn, R, Z, v once and
+// writes cam_attn, cam_v; QK reads R_nn, Z_qk, q, k once and writes cam_q, cam_k = the rules' algorithmic bytes (the
+// 64 x 64-tile kernels of te_attn_mfma.hip wrote S to a workspace and re-read it and attn: ~8 N^2 passes per layer).
+// N > 256: the keys are cut into groups of <= 256 (one workgroup each); the column side of a group is complete, the
+// QK rule's row side (cam_q) is a per-group partial that a small finishing kernel sums in group order.
+//
+// All reductions run in a fixed order that depends on N only: a batch equals its samples run one by one, bit for bit.
+// LDS images: [rows][64] tiles with the 16-B chunks of a row XOR-ed by (row & 15) (conflict-free ds_read_b128 over
+// 16 rows, conflict-free ds_read_b32 along a row); the [32][256] tile the same within each group of 16 chunks.
+#include <stdlib.h>
+#include <string.h>
+
+#include "te_common.h"
+
+namespace te_attn_rules {
+
+namespace {
+
+constexpr int TI = 32;         // query rows per tile
+constexpr int kT = 512;        // threads per workgroup
+constexpr int kWaves = kT / 64;
+constexpr int NJMAX = 256;     // keys per workgroup
+constexpr int WLD = 256;       // row stride of the [TI][keys] tile
+
+struct Strided {  // [B,H,N,D] view, D contiguous
+  int64_t sb, sh, sn;
+};
+
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+#define TE_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define TE_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ (row & 15)) << 2); }
+__device__ __forceinline__ int swzw(int row, int chunk) {
+  return row * WLD + (((chunk & ~15) | ((chunk ^ row) & 15)) << 2);
+}
+// element (row, x) of a swizzled tile
+__device__ __forceinline__ float at64(const float* __restrict__ T, int row, int x) {
+  return T[swz64(row, x >> 2) + (x & 3)];
+}
+__device__ __forceinline__ float atw(const float* __restrict__ T, int row, int x) {
+  return T[swzw(row, x >> 2) + (x & 3)];
+}
+__device__ __forceinline__ int crow(int e, int kh) { return (e & 3) + 8 * (e >> 2) + 4 * kh; }
+
+__device__ __forceinline__ void zero16(f32x16& a) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) a[e] = 0.0f;
+}
+
+// guarded 4-wide access at a dword-aligned address: elements [c, c+4) of a row with `cols_valid` valid columns
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int c, int cols_valid) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (c + 3 < cols_valid) {
+    v = *reinterpret_cast<const f32x4_u*>(p + c);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < cols_valid) v[e] = p[c + e];
+  }
+  return v;
+}
+
+// The [TI][nj] tile of an [N,N] operand in flight: thread t holds float4 slots idx = t + 512 r (r < 4) of the
+// [TI][NJ32 / 4] float4 grid; (row, c4) per slot are loop-invariant.
+struct WideTile {
+  f32x4 v[4];
+};
+struct WideMap {
+  int row[4], c4[4];   // row < 0: no slot
+};
+__device__ __forceinline__ WideMap wide_map(int nj32) {
+  WideMap m;
+  const int per_row = nj32 >> 2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = threadIdx.x + r * kT;
+    const int row = idx / per_row;
+    m.row[r] = (row < TI) ? row : -1;
+    m.c4[r] = idx - row * per_row;
+  }
+  return m;
+}
+__device__ __forceinline__ void load_wide(WideTile& t, const WideMap& m, const float* __restrict__ src, int64_t ld,
+                                          int rows_valid, int cols_valid) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m.row[r] >= 0 && m.row[r] < rows_valid) v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid);
+    t.v[r] = v;
+  }
+}
+__device__ __forceinline__ void store_wide(float* __restrict__ lds, const WideMap& m, const WideTile& t) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m.row[r] >= 0) *reinterpret_cast<f32x4*>(lds + swzw(m.row[r], m.c4[r])) = t.v[r];
+}
+
+// key-side operand (v or k) of this group: rows [j0, j0 + nj) -> LDS [nj32][64], rows >= nj zero
+__device__ __forceinline__ void stage_keys(float* __restrict__ Kt, const float* __restrict__ src, int64_t sn, int nj,
+                                           int nj32) {
+  for (int idx = threadIdx.x; idx < nj32 * 16; idx += kT) {
+    const int row = idx >> 4, c = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nj) v = *reinterpret_cast<const f32x4_u*>(src + (int64_t)row * sn + (c << 2));
+    *reinterpret_cast<f32x4*>(Kt + swz64(row, c)) = v;
+  }
+}
+
+// column-side product of one row tile:  acc[(jb, db)] += W^T[keys x 32] Yt[32 x 64], 32x32 blocks t = 2 jb + db,
+// wave w owns t = w and t = w + 8
+__device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __restrict__ Wt, const float* __restrict__ Yt,
+                                            int wave, int lr, int kh, int nblk) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = wave + s * kWaves;
+    if (t < nblk) {
+      const int jx = (t >> 1) * 32 + lr, dx = (t & 1) * 32 + lr;
+#pragma unroll
+      for (int kg = 0; kg < TI / 8; ++kg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = kg * 8 + kh * 4 + j;
+          acc[s] = TE_MFMA32(atw(Wt, k, jx), at64(Yt, k, dx), acc[s]);
+        }
+    }
+  }
+}
+
+// out[j0 + j, d] = X[j, d] * acc * scale for the blocks of col_product (X = the resident key-side LDS image)
+__device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float* __restrict__ Kt, float* __restrict__ out,
+                                             int64_t osn, int nj, int wave, int lr, int kh, int nblk, float scale) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = wave + s * kWaves;
+    if (t < nblk) {
+      const int d = (t & 1) * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int j = (t >> 1) * 32 + crow(e, kh);
+        if (j < nj) out[(int64_t)j * osn + d] = (at64(Kt, j, d) * acc[s][e]) * scale;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AV rule.  R strided [B,H,N,64]; Z contiguous [B*H,N,64]; attn, cam_attn contiguous [B*H,N,N]; v, cam_v strided.
+// grid = BH * ngroups (bh fastest: with BH a multiple of 8 a (b,h)'s groups share an XCD)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void av_rule_kernel(
+    const float* __restrict__ R, Strided rs, const float* __restrict__ Z, const float* __restrict__ attn,
+    const float* __restrict__ v, Strided vs, float* __restrict__ cam_attn, float* __restrict__ cam_v, Strided cs, int H,
+    int N, int BH, int JG, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vt = smem;                    // [NJMAX][64]
+  float* St = Vt + NJMAX * 64;         // [TI][64]
+  float* Wt = St + TI * 64;            // [TI][256]: the attn tile
+  const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
+  const int b = bh / H, h = bh % H;
+  const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  const float* r_bh = R + (int64_t)b * rs.sb + (int64_t)h * rs.sh;
+  const float* z_bh = Z + (int64_t)bh * N * 64;
+  const float* a_bh = attn + (int64_t)bh * N * N + j0;
+  float* ca_bh = cam_attn + (int64_t)bh * N * N + j0;
+  const float* v_bh = v + (int64_t)b * vs.sb + (int64_t)h * vs.sh + (int64_t)j0 * vs.sn;
+  const int ntiles = (N + TI - 1) / TI;
+  const WideMap wm = wide_map(nj32);
+  const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;      // this thread's float4 of the [32][64] S tile
+
+  stage_keys(Vt, v_bh, vs.sn, nj, nj32);
+  WideTile ta;
+  f32x4 rr = {0.f, 0.f, 0.f, 0.f}, zz = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int it) __attribute__((always_inline)) {
+    const int i0 = it * TI, rows_valid = min(TI, N - i0);
+    load_wide(ta, wm, a_bh + (int64_t)i0 * N, N, rows_valid, nj);
+    rr = zz = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (srow < rows_valid) {
+      rr = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(i0 + srow) * rs.sn + (sc << 2));
+      zz = *reinterpret_cast<const f32x4_u*>(z_bh + (int64_t)(i0 + srow) * 64 + (sc << 2));
+    }
+  };
+  fetch(0);
+  f32x16 accv[2];
+  zero16(accv[0]);
+  zero16(accv[1]);
+  for (int it = 0; it < ntiles; ++it) {
+    const int i0 = it * TI;
+    __syncthreads();                       // the previous tile's readers are done (first trip: nothing to wait for)
+    {
+      f32x4 s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);     // rows beyond N: sd(0, 0) = 0
+      *reinterpret_cast<f32x4*>(St + swz64(srow, sc)) = s;
+      store_wide(Wt, wm, ta);
+    }
+    __syncthreads();
+    if (it + 1 < ntiles) fetch(it + 1);
+    if (wave < njb) {
+      // G = S v^T for key block `wave`; cam_attn = attn . G
+      f32x16 gacc;
+      zero16(gacc);
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(St + swz64(lr, kg * 2 + kh));
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(Vt + swz64(wave * 32 + lr, kg * 2 + kh));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gacc = TE_MFMA32(a[j], bq[j], gacc);
+      }
+      const int jl = wave * 32 + lr;
+      if (jl < nj) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int il = crow(e, kh);
+          if (i0 + il < N) ca_bh[(int64_t)(i0 + il) * N + jl] = (atw(Wt, il, jl) * gacc[e]) * scale;
+        }
+      }
+    }
+    col_product(accv, Wt, St, wave, lr, kh, 2 * njb);
+  }
+  float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
+  col_epilogue(accv, Vt, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
+}
+
+// ------------------------------------------------------------------------------------------------
+// QK rule.  Rnn, Z contiguous [B*H,N,N]; q, k, cam_q, cam_k strided.  ngroups > 1: cam_q goes to `qpart`
+// [ngroups][B*H][N][64] unscaled (qk_finish_kernel folds the groups); cam_k of a group is complete.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void qk_rule_kernel(
+    const float* __restrict__ Rnn, const float* __restrict__ Z, const float* __restrict__ q, Strided qs,
+    const float* __restrict__ k, Strided ks, float* __restrict__ cam_q, Strided cqs, float* __restrict__ cam_k,
+    Strided cks, float* __restrict__ qpart, int H, int N, int BH, int JG, int ngroups, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Kt = smem;                    // [NJMAX][64]
+  float* Qt = Kt + NJMAX * 64;         // [TI][64]
+  float* Wt = Qt + TI * 64;            // [TI][256]: the S tile
+  const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
+  const int b = bh / H, h = bh % H;
+  const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  const float* r_bh = Rnn + (int64_t)bh * N * N + j0;
+  const float* z_bh = Z + (int64_t)bh * N * N + j0;
+  const float* q_bh = q + (int64_t)b * qs.sb + (int64_t)h * qs.sh;
+  const float* k_bh = k + (int64_t)b * ks.sb + (int64_t)h * ks.sh + (int64_t)j0 * ks.sn;
+  const int ntiles = (N + TI - 1) / TI;
+  const WideMap wm = wide_map(nj32);
+  const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
+
+  stage_keys(Kt, k_bh, ks.sn, nj, nj32);
+  WideTile tr, tz;
+  f32x4 qq = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int it) __attribute__((always_inline)) {
+    const int i0 = it * TI, rows_valid = min(TI, N - i0);
+    load_wide(tr, wm, r_bh + (int64_t)i0 * N, N, rows_valid, nj);
+    load_wide(tz, wm, z_bh + (int64_t)i0 * N, N, rows_valid, nj);
+    qq = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (srow < rows_valid) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * qs.sn + (sc << 2));
+  };
+  fetch(0);
+  f32x16 acck[2];
+  zero16(acck[0]);
+  zero16(acck[1]);
+  // cam_q: eight 16x16 output blocks of the [32][64] tile, one per wave
+  const int ib = wave >> 2, db = wave & 3, l15 = lane & 15, kq = lane >> 4;
+  for (int it = 0; it < ntiles; ++it) {
+    const int i0 = it * TI;
+    __syncthreads();
+    {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tr.v[r][e] = te_sd(tr.v[r][e], tz.v[r][e]);   // zero-filled slots: sd(0, 0) = 0
+      store_wide(Wt, wm, tr);
+      *reinterpret_cast<f32x4*>(Qt + swz64(srow, sc)) = qq;
+    }
+    __syncthreads();
+    if (it + 1 < ntiles) fetch(it + 1);
+    {
+      // cam_q block (ib, db) = S[16 x keys] k[keys x 16]
+      f32x4 cq = {0.f, 0.f, 0.f, 0.f};
+      const int arow = ib * 16 + l15, dcol = db * 16 + l15;
+      for (int kg = 0; kg < (nj32 >> 4); ++kg) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kg * 4 + kq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cq = TE_MFMA16(a[j], at64(Kt, kg * 16 + kq * 4 + j, dcol), cq);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = ib * 16 + kq * 4 + r;
+        if (i0 + il < N) {
+          if (ngroups == 1) {
+            cam_q[(int64_t)b * cqs.sb + (int64_t)h * cqs.sh + (int64_t)(i0 + il) * cqs.sn + dcol] =
+                (at64(Qt, il, dcol) * cq[r]) * scale;
+          } else {
+            qpart[(((int64_t)g * BH + bh) * N + i0 + il) * 64 + dcol] = cq[r];
+          }
+        }
+      }
+    }
+    col_product(acck, Wt, Qt, wave, lr, kh, 2 * njb);
+  }
+  float* o_bh = cam_k + (int64_t)b * cks.sb + (int64_t)h * cks.sh + (int64_t)j0 * cks.sn;
+  col_epilogue(acck, Kt, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
+}
+
+// cam_q[i,d] = q[i,d] * (sum over groups of qpart[g][bh][i][d], in group order) * scale
+__global__ __launch_bounds__(256) void qk_finish_kernel(const float* __restrict__ qpart, const float* __restrict__ q,
+                                                        Strided qs, float* __restrict__ cam_q, Strided cqs, int H, int N,
+                                                        int BH, int ngroups, float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index into [BH][N][16]
+  if (idx >= (int64_t)BH * N * 16) return;
+  const int c = (int)(idx & 15);
+  const int64_t row = idx >> 4;
+  const int i = (int)(row % N), bh = (int)(row / N), b = bh / H, h = bh % H;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < ngroups; ++g) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(qpart + (((int64_t)g * BH + bh) * N + i) * 64 + (c << 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = s[e] + p[e];
+  }
+  const f32x4 qv = *reinterpret_cast<const f32x4_u*>(q + (int64_t)b * qs.sb + (int64_t)h * qs.sh + (int64_t)i * qs.sn + (c << 2));
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (qv[e] * s[e]) * scale;
+  *reinterpret_cast<f32x4_u*>(cam_q + (int64_t)b * cqs.sb + (int64_t)h * cqs.sh + (int64_t)i * cqs.sn + (c << 2)) = o;
+}
+
+constexpr size_t kLds = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD) * sizeof(float);   // 104 KB
+
+inline void groups_for(int64_t N, int& ng, int& jg) {
+  ng = (int)((N + NJMAX - 1) / NJMAX);
+  jg = (int)(((N + ng - 1) / ng + 31) & ~(int64_t)31);      // equal groups, rounded up to whole 32-key blocks
+}
+
+}  // namespace
+
+bool enabled() {
+  // TE_ATTN_IMPL=tiles selects the 64 x 64-tile kernels of te_attn_mfma.hip (kept as the on-device cross-check)
+  static const bool on = [] {
+    const char* e = getenv("TE_ATTN_IMPL");
+    return !(e && !strcmp(e, "tiles"));
+  }();
+  return on;
+}
+
+bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
+  int ng, jg;
+  groups_for(N, ng, jg);
+  return D == 64 && N >= 1 && N <= 4096 && B * H * ng <= 0x7fffffff;
+}
+
+// extra workspace (floats) of the QK rule beyond Z: the per-group cam_q partials
+size_t qk_partial_floats(int64_t B, int64_t H, int64_t N) {
+  int ng, jg;
+  groups_for(N, ng, jg);
+  return ng > 1 ? (size_t)ng * B * H * N * 64 : 0;
+}
+
+int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn, const float* v, int64_t v_sb,
+              int64_t v_sh, int64_t v_sn, const float* Z, float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh,
+              int64_t cv_sn, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream) {
+  int ng, jg;
+  groups_for(N, ng, jg);
+  const int BH = (int)(B * H);
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(av_rule_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kLds);
+    return true;
+  }();
+  (void)once;
+  av_rule_kernel<<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(
+      R, Strided{r_sb, r_sh, r_sn}, Z, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v, Strided{cv_sb, cv_sh, cv_sn},
+      (int)H, (int)N, BH, jg, scale);
+  return TE_OK;
+}
+
+int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
+              int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
+              float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
+              float* qpart, hipStream_t stream) {
+  int ng, jg;
+  groups_for(N, ng, jg);
+  const int BH = (int)(B * H);
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qk_rule_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)kLds);
+    return true;
+  }();
+  (void)once;
+  const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
+  qk_rule_kernel<<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k, cks,
+                                                                        qpart, (int)H, (int)N, BH, jg, ng, scale);
+  if (ng > 1) {
+    const int64_t n4 = (int64_t)BH * N * 16;
+    qk_finish_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(qpart, q, qs, cam_q, cqs, (int)H,
+                                                                                  (int)N, BH, ng, scale);
+  }
+  return TE_OK;
+}
+
+}  // namespace te_attn_rules

@@ -128,19 +128,33 @@ __global__ __launch_bounds__(64) void rollout_cls_fixup_kernel(float* __restrict
 
 // ---- row-0 chain ------------------------------------------------------------------------------------------------
 constexpr int kRowSlab = 16;      // rows of M_i per block
-constexpr int kRowMaxJ = 16;      // columns per lane: N <= 64 * 16 = 1024
+constexpr int kRowMaxJ = 16;      // most columns per lane: N <= 64 * 16 = 1024
 
 // partial_out[b, slab, :] = sum_{k in slab} r[k] * M[k, :],  M = (A + I) [/ rowsum(A + I)]
 //   r[k] = sum over the previous step's slabs of partial_in[b, slab', k]  (fixed order), or e_0 when FIRST
-template <bool FIRST>
+template <bool FIRST, int MJ>     // MJ columns per lane: N <= 64 * MJ
 __global__ __launch_bounds__(kThreads) void rollout_row_step_kernel(
     const float* __restrict__ A, const float* __restrict__ partial_in, float* __restrict__ partial_out, int N,
     int nslab_in, int normalise) {
   __shared__ float r_s[kRowSlab];
-  __shared__ float fold[kThreads / 64 - 1][64 * kRowMaxJ];
+  __shared__ float fold[kThreads / 64 - 1][64 * MJ];
+  constexpr int RPW = kRowSlab / (kThreads / 64);      // rows per wave
   const int b = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k0 = slab * kRowSlab, k1 = min(N, k0 + kRowSlab);
+  const float* a_b = A + (int64_t)b * N * N;
+  // this wave's rows of M (k = k0 + wave + 4 u), requested before anything waits: e_0^T M needs row 0 only
+  const int kend = FIRST ? min(k1, 1) : k1;
+  float v[RPW][MJ];
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int k = k0 + wave + u * (kThreads / 64);
+#pragma unroll
+    for (int m = 0; m < MJ; ++m) {
+      const int j = lane + 64 * m;
+      v[u][m] = (k < kend && j < N) ? a_b[(int64_t)k * N + j] : 0.0f;
+    }
+  }
   if (threadIdx.x < kRowSlab) {
     const int k = k0 + threadIdx.x;
     float r = 0.0f;
@@ -148,49 +162,56 @@ __global__ __launch_bounds__(kThreads) void rollout_row_step_kernel(
       if constexpr (FIRST) {
         r = (k == 0) ? 1.0f : 0.0f;
       } else {
+        // slab order, loads issued 16 at a time (a plain loop waits for every load before the next add)
         const float* p = partial_in + (int64_t)b * nslab_in * N + k;
-        for (int s = 0; s < nslab_in; ++s) r = r + p[(int64_t)s * N];
+        for (int s0 = 0; s0 < nslab_in; s0 += 16) {
+          float t[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) t[u] = (s0 + u < nslab_in) ? p[(int64_t)(s0 + u) * N] : 0.0f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) r = r + t[u];
+        }
       }
     }
     r_s[threadIdx.x] = r;
   }
   __syncthreads();
-  float acc[kRowMaxJ];
+  float acc[MJ];
 #pragma unroll
-  for (int m = 0; m < kRowMaxJ; ++m) acc[m] = 0.0f;
-  const float* a_b = A + (int64_t)b * N * N;
-  const int kend = FIRST ? min(k1, 1) : k1;      // e_0^T M needs row 0 only
-  for (int k = k0 + wave; k < kend; k += kThreads / 64) {
-    const float rk = r_s[k - k0];
-    const float* row = a_b + (int64_t)k * N;
-    float v[kRowMaxJ];
+  for (int m = 0; m < MJ; ++m) acc[m] = 0.0f;
 #pragma unroll
-    for (int m = 0; m < kRowMaxJ; ++m) {
-      const int j = lane + 64 * m;
-      v[m] = (j < N) ? (row[j] + (j == k ? 1.0f : 0.0f)) : 0.0f;
+  for (int u = 0; u < RPW; ++u) {
+    const int k = k0 + wave + u * (kThreads / 64);
+    if (k < kend) {                      // wave-uniform
+      const float rk = r_s[k - k0];
+#pragma unroll
+      for (int m = 0; m < MJ; ++m) {
+        const int j = lane + 64 * m;
+        if (j < N) v[u][m] = v[u][m] + (j == k ? 1.0f : 0.0f);
+      }
+      if (normalise) {
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < MJ; ++m)
+          if (lane + 64 * m < N) s += (double)v[u][m];
+        s = te_wave_sum(s);
+        const float den = (float)__shfl(s, 0, 64);
+#pragma unroll
+        for (int m = 0; m < MJ; ++m) v[u][m] = v[u][m] / den;
+      }
+#pragma unroll
+      for (int m = 0; m < MJ; ++m) acc[m] = fmaf(rk, v[u][m], acc[m]);
     }
-    if (normalise) {
-      double s = 0.0;
-#pragma unroll
-      for (int m = 0; m < kRowMaxJ; ++m)
-        if (lane + 64 * m < N) s += (double)v[m];
-      s = te_wave_sum(s);
-      const float den = (float)__shfl(s, 0, 64);
-#pragma unroll
-      for (int m = 0; m < kRowMaxJ; ++m) v[m] = v[m] / den;
-    }
-#pragma unroll
-    for (int m = 0; m < kRowMaxJ; ++m) acc[m] = fmaf(rk, v[m], acc[m]);
   }
   if (wave > 0) {
 #pragma unroll
-    for (int m = 0; m < kRowMaxJ; ++m) fold[wave - 1][m * 64 + lane] = acc[m];
+    for (int m = 0; m < MJ; ++m) fold[wave - 1][m * 64 + lane] = acc[m];
   }
   __syncthreads();
   if (wave == 0) {
     float* out = partial_out + ((int64_t)b * nslab + slab) * N;
 #pragma unroll
-    for (int m = 0; m < kRowMaxJ; ++m) {
+    for (int m = 0; m < MJ; ++m) {
       const int j = lane + 64 * m;
       float t = acc[m];
 #pragma unroll
@@ -210,7 +231,13 @@ __global__ __launch_bounds__(kThreads) void rollout_row_finish_kernel(const floa
   float mn = INFINITY;
   for (int j = threadIdx.x; j < N; j += kThreads) {
     float r = 0.0f;
-    for (int s = 0; s < nslab; ++s) r = r + p[(int64_t)s * N + j];
+    for (int s0 = 0; s0 < nslab; s0 += 16) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = (s0 + u < nslab) ? p[(int64_t)(s0 + u) * N + j] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) r = r + t[u];
+    }
     out[(int64_t)b * N + j] = r;
     mn = fminf(mn, r);
   }
@@ -257,12 +284,20 @@ extern "C" int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer,
     const dim3 grid((unsigned)nslab, (unsigned)B), blk(kThreads);
     int cur = 0;
     // e_0^T M_{L-1}: only slab 0 has a non-zero row, the others write zeros (uniform fold in the next step)
-    rollout_row_step_kernel<true><<<grid, blk, 0, stream>>>(cams + (L - 1) * mat, nullptr, pp[cur], (int)N, 0, norm);
-    for (int64_t i = L - 2; i >= start_layer; --i) {
-      rollout_row_step_kernel<false><<<grid, blk, 0, stream>>>(cams + i * mat, pp[cur], pp[cur ^ 1], (int)N, nslab,
-                                                               norm);
-      cur ^= 1;
-    }
+#define TE_ROW_STEPS(MJ_)                                                                                           \
+  do {                                                                                                             \
+    rollout_row_step_kernel<true, MJ_><<<grid, blk, 0, stream>>>(cams + (L - 1) * mat, nullptr, pp[cur], (int)N, 0, \
+                                                                 norm);                                            \
+    for (int64_t i = L - 2; i >= start_layer; --i) {                                                               \
+      rollout_row_step_kernel<false, MJ_><<<grid, blk, 0, stream>>>(cams + i * mat, pp[cur], pp[cur ^ 1], (int)N,   \
+                                                                    nslab, norm);                                  \
+      cur ^= 1;                                                                                                    \
+    }                                                                                                              \
+  } while (0)
+    if (N <= 256) TE_ROW_STEPS(4);
+    else if (N <= 640) TE_ROW_STEPS(10);
+    else TE_ROW_STEPS(16);
+#undef TE_ROW_STEPS
     rollout_row_finish_kernel<<<dim3((unsigned)B), blk, 0, stream>>>(pp[cur], joint, (int)N, nslab,
                                                                     (flags & TE_ROLLOUT_CLS_FIXUP) ? 1 : 0);
     TE_RETURN_IF_LAUNCH_FAILED();
