@@ -304,10 +304,24 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
       // cam_q block (ib, db) = S[16 x keys] k[keys x 16]
       f32x4 cq = {0.f, 0.f, 0.f, 0.f};
       const int arow = ib * 16 + l15, dcol = db * 16 + l15;
-      for (int kg = 0; kg < (nj32 >> 4); ++kg) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kg * 4 + kq));
+      // K = the group's keys, 32 per trip (nj32 is a multiple of 32): both A fragments and all eight B values of a
+      // trip are requested before its first MFMA, and two trips are unrolled so that the next trip's LDS reads issue
+      // under the current trip's MFMAs
+#pragma unroll 2
+      for (int kp = 0; kp < (nj32 >> 5); ++kp) {
+        f32x4 a[2];
+        float bv[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cq = TE_MFMA16(a[j], at64(Kt, kg * 16 + kq * 4 + j, dcol), cq);
+        for (int u = 0; u < 2; ++u) {
+          const int kg = kp * 2 + u;
+          a[u] = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kg * 4 + kq));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[u][j] = at64(Kt, kg * 16 + kq * 4 + j, dcol);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cq = TE_MFMA16(a[u][j], bv[u][j], cq);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
