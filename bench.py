@@ -175,9 +175,12 @@ KERNEL_GROUPS = {
     "linear_cpass": ("linear_k2_kernel<0,false,false>", "Linear.relprop C-pass, layers_ours.py:220-225"),
     "linear_zpass_fwd": ("linear_k1_kernel<ZM_FWD>", "Linear.relprop Z-pass from the forward output, layers_ours.py:216-219"),
     "linear_zpass": ("linear_k1_kernel<ZM_OURS>", "Linear.relprop Z-pass (two products), layers_ours.py:216-219"),
-    "attention_av_rule": ("av_row_kernel + col_kernel", "einsum 'bhij,bhjd->bhid' / MatMul rule, layers_ours.py:48-60"),
-    "attention_qk_rule": ("qk_row_kernel + col_kernel", "einsum 'bhid,bhjd->bhij' / MatMul rule, layers_ours.py:48-60"),
+    "attention_av_rule": ("av_rule_kernel", "einsum 'bhij,bhjd->bhid' / MatMul rule, layers_ours.py:48-60"),
+    "attention_qk_rule": ("qk_rule_kernel", "einsum 'bhid,bhjd->bhij' / MatMul rule, layers_ours.py:48-60"),
     "attention_fused_rules": ("attn_rules_kernel", "both attention rules of a ViT block in one pass, ViT_LRP.py:157-173"),
+    "attention_forward": ("attn_fwd_kernel", "producer: scores + softmax + attn v, ViT_LRP.py:132-152"),
+    "attention_backward": ("av_rule_kernel<BWD> + qk_rule_kernel<BWD>", "producer: attention-gradient backward, "
+                                                                         "ViT_LRP.py:144-145"),
     "add_deferred": ("add_deferred_kernel + add_factors_kernel", "Add.relprop (one pass; rescale applied by the "
                                                                  "consumers), layers_ours.py:97-120"),
     "add": ("add_sums_kernel + add_apply_kernel", "Add.relprop, layers_ours.py:97-120"),

@@ -140,6 +140,18 @@ int te_matmul_relprop_av_fwd_f32(const float* R, int64_t r_sb, int64_t r_sh, int
                                  float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
                                  int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
                                  void* ws, size_t ws_bytes, te_stream_t stream);
+/* te_matmul_relprop_av_fwd_f32 with a STRIDED Z (element (b,h,n,d) at Z + b*z_sb + h*z_sh + n*z_sn + d): the forward
+ * product attn v usually lives only as the 'b n (h d)' activation that feeds the output projection (ViT_LRP.py:148);
+ * z_sb = N*C, z_sh = D, z_sn = C reads it in place.  One-pass kernels only (head dim 64): TE_ERR_UNSUPPORTED otherwise
+ * (callers then pass a contiguous copy to te_matmul_relprop_av_fwd_f32). */
+int te_matmul_relprop_av_fwdz_f32(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn,
+                                  const float* attn,
+                                  const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                                  const float* Z, int64_t z_sb, int64_t z_sh, int64_t z_sn,
+                                  float* cam_attn,
+                                  float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
+                                  int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
+                                  void* ws, size_t ws_bytes, te_stream_t stream);
 int te_matmul_relprop_qk_fwd_f32(const float* R_nn,
                                  const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
                                  const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
@@ -227,6 +239,22 @@ size_t te_rollout_workspace_bytes(int64_t L, int64_t B, int64_t N);
 size_t te_rollout_row0_workspace_bytes(int64_t B, int64_t N);
 int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
                    int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* ---- producers of the cached tensors ----------------------------------------------------
+ * The attention block of baselines/ViT/ViT_LRP.py:132-152 (and its gradient, the tensor save_attn_gradients receives,
+ * :144-145) on the fused qkv activation [B,N,3*H*D] ('b n (qkv h d)'), head dim 64, N <= 224 (k and v of a head stay
+ * in LDS; te_attention_forward_supported says whether a shape qualifies -- callers keep stock PyTorch otherwise):
+ *   forward : z_qk [B,H,N,N] = q k^T (unscaled: the QK rule's Z) ; attn [B,H,N,N] = softmax(z_qk * scale) ;
+ *             out [B,N,H*D] = attn v in the 'b n (h d)' layout the projection consumes (= the AV rule's Z, strided)
+ *   backward: d_attn [B,H,N,N] = d_out v^T (the attention gradient of the explanation) ; d_qkv [B,N,3*H*D]:
+ *             d_v = attn^T d_out always ; need_qk != 0 additionally d_s = attn .(d_attn - rowsum(d_attn . attn)) * scale,
+ *             d_q = d_s k, d_k = d_s^T q (need_qk == 0: the q / k thirds of d_qkv are left untouched -- the lowest
+ *             block whose attention gradient is wanted has no consumer for them). */
+int te_attention_forward_supported(int64_t N, int64_t D);
+int te_attention_forward_f32(const float* qkv, float* z_qk, float* attn, float* out,
+                             int64_t B, int64_t H, int64_t N, int64_t D, float scale, te_stream_t stream);
+int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn, float* d_qkv,
+                              int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk, te_stream_t stream);
 
 /* ---- consumer of a relevance map ---------------------------------------------------
  * replaces baselines/ViT/imagenet_seg_eval.py:214-222 and generate_visualizations.py:99-100 (per map):

@@ -16,6 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libte_relprop.so")
 
 TE_OK = 0
+TE_ERR_UNSUPPORTED = -3
 TE_VARIANT_OURS = 0
 TE_VARIANT_LRP = 1
 TE_IMPL_SIMPLE = 0x100
@@ -44,6 +45,11 @@ SIGNATURES = {
     "te_matmul_relprop_qk_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I64]),
     "te_matmul_relprop_av_fwd_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64,
                                           _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
+    "te_matmul_relprop_av_fwdz_f32": (_I, [_P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P,
+                                           _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
+    "te_attention_forward_supported": (_I, [_I64, _I64]),
+    "te_attention_forward_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P]),
+    "te_attention_backward_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "te_matmul_relprop_qk_fwd_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
                                           _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_matmul_relprop_qk_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64,

@@ -18,9 +18,9 @@ namespace te_attn_mfma {
 // implemented in te_attn_mfma.hip; return false if the shape is not supported by the tiled kernels
 bool av_supported(int64_t N, int64_t D);
 int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn,
-              const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* Z, float* cam_attn, float* cam_v,
-              int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N, int64_t D,
-              float scale, float* ws, hipStream_t stream);
+              const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* Z, int64_t z_sb, int64_t z_sh,
+              int64_t z_sn, float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B,
+              int64_t H, int64_t N, int64_t D, float scale, float* ws, hipStream_t stream);
 bool qk_supported(int64_t N, int64_t D);
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
               const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb,
@@ -159,20 +159,33 @@ extern "C" int te_matmul_relprop_av_fwd_f32(const float* R, int64_t r_sb, int64_
                                             int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H,
                                             int64_t N, int64_t D, float out_scale, int variant, void* ws,
                                             size_t ws_bytes, te_stream_t stream_) {
+  return te_matmul_relprop_av_fwdz_f32(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, H * N * D, N * D, D, cam_attn,
+                                       cam_v, cv_sb, cv_sh, cv_sn, B, H, N, D, out_scale, variant, ws, ws_bytes, stream_);
+}
+
+extern "C" int te_matmul_relprop_av_fwdz_f32(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn,
+                                             const float* attn, const float* v, int64_t v_sb, int64_t v_sh,
+                                             int64_t v_sn, const float* Z, int64_t z_sb, int64_t z_sh, int64_t z_sn,
+                                             float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh,
+                                             int64_t cv_sn, int64_t B, int64_t H, int64_t N, int64_t D,
+                                             float out_scale, int variant, void* ws, size_t ws_bytes,
+                                             te_stream_t stream_) {
   if (!R || !attn || !v || !cam_attn || !cam_v || B <= 0 || H <= 0 || N <= 0 || D <= 0)
     return TE_ERR_INVALID_ARG;
+  const bool z_contig = !Z || (z_sn == D && z_sh == N * D && z_sb == H * N * D);
   if (!strides_ok(r_sb, r_sh, r_sn) || !strides_ok(v_sb, v_sh, v_sn) || !strides_ok(cv_sb, cv_sh, cv_sn))
     return TE_ERR_INVALID_ARG;
   if (!ws || ws_bytes < te_matmul_relprop_av_workspace_bytes(B, H, N, D)) return TE_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* S = (float*)ws;
   if (!(variant & TE_IMPL_SIMPLE) && te_attn_mfma::av_supported(N, D)) {
-    int rc = te_attn_mfma::av_launch(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, cam_attn, cam_v, cv_sb,
-                                     cv_sh, cv_sn, B, H, N, D, out_scale, S, stream);
+    int rc = te_attn_mfma::av_launch(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, z_sb, z_sh, z_sn, cam_attn,
+                                     cam_v, cv_sb, cv_sh, cv_sn, B, H, N, D, out_scale, S, stream);
     if (rc != TE_OK) return rc;
     TE_RETURN_IF_LAUNCH_FAILED();
     return TE_OK;
   }
+  if (!z_contig) return TE_ERR_UNSUPPORTED;      // the simple kernels read Z as contiguous [B,H,N,D]
   const Strided rs{r_sb, r_sh, r_sn}, vs{v_sb, v_sh, v_sn}, cs{cv_sb, cv_sh, cv_sn};
   const int64_t nd = B * H * N * D, nn = B * H * N * N;
   dim3 blk(kThreads);

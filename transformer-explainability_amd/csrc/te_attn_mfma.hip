@@ -28,8 +28,9 @@ namespace te_attn_rules {   // te_attn_rules.hip: the one-pass rule kernels (def
 bool enabled();
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
 int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn, const float* v, int64_t v_sb,
-              int64_t v_sh, int64_t v_sn, const float* Z, float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh,
-              int64_t cv_sn, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream);
+              int64_t v_sh, int64_t v_sn, const float* Z, int64_t z_sb, int64_t z_sh, int64_t z_sn, float* cam_attn,
+              float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N, float scale,
+              hipStream_t stream);
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
               int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
               float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
@@ -510,10 +511,11 @@ bool qk_supported(int64_t N, int64_t D) { return D == TS && N >= 1 && N <= (1 <<
 
 // workspace (floats): S [B*H,N,64] followed by Z [B*H,N,64] (used only when the caller passes Z == NULL)
 int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn, const float* v,
-              int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* Z, float* cam_attn, float* cam_v, int64_t cv_sb,
-              int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N, int64_t D, float scale, float* ws,
-              hipStream_t stream) {
+              int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* Z, int64_t z_sb, int64_t z_sh, int64_t z_sn,
+              float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H,
+              int64_t N, int64_t D, float scale, float* ws, hipStream_t stream) {
   if (D != TS) return TE_ERR_UNSUPPORTED;
+  const bool z_contig = !Z || (z_sn == TS && z_sh == N * TS && z_sb == H * N * TS);
   const int BH = (int)(B * H);
   const int nt = (int)((N + TS - 1) / TS);
   const Strided rs{r_sb, r_sh, r_sn}, vs{v_sb, v_sh, v_sn}, cs{cv_sb, cv_sh, cv_sn};
@@ -524,10 +526,12 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
     float* wsZ = ws + (size_t)BH * N * TS;
     z_av_kernel<<<grid, blk, 0, stream>>>(attn, v, vs, wsZ, (int)H, (int)N, BH);
     Z = wsZ;
+    z_sb = H * N * TS, z_sh = N * TS, z_sn = TS;
   }
   if (te_attn_rules::enabled() && te_attn_rules::supported(B, H, N, D))
-    return te_attn_rules::av_launch(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, cam_attn, cam_v, cv_sb, cv_sh,
-                                    cv_sn, B, H, N, scale, stream);
+    return te_attn_rules::av_launch(R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, z_sb, z_sh, z_sn, cam_attn, cam_v,
+                                    cv_sb, cv_sh, cv_sn, B, H, N, scale, stream);
+  if (!z_contig) return TE_ERR_UNSUPPORTED;      // the 64 x 64-tile kernels read Z as contiguous [B*H,N,64]
   av_row_kernel<<<grid, blk, 0, stream>>>(R, rs, Z, attn, v, vs, cam_attn, wsS, (int)H, (int)N, BH, scale);
   col_kernel<<<grid, blk, 0, stream>>>(attn, wsS, ss, v, vs, cam_v, cs, (int)H, (int)N, BH, scale);
   return TE_OK;

@@ -27,6 +27,15 @@
 // N > 256: the keys are cut into groups of <= 256 (one workgroup each); the column side of a group is complete, the
 // QK rule's row side (cam_q) is a per-group partial that a small finishing kernel sums in group order.
 //
+// Producers on the same machinery, N <= 224 (k AND v resident), head dim 64:
+//   attn_fwd_kernel          z_qk = q k^T (unscaled, written for the QK rule), attn = softmax(z_qk * scale) over the
+//                            LDS tile, out = attn v written as 'b n (h d)' -- ViT_LRP.py:132-152 in one pass over
+//                            the fused qkv activation (no q/k/v copies, no separate scale / softmax / transpose passes)
+//   av_rule_kernel<BWD>      attention-gradient backward, first half: d_attn = d_out v^T (the tensor
+//                            save_attn_gradients receives, ViT_LRP.py:144-145) and d_v = attn^T d_out
+//   qk_rule_kernel<BWD>      second half: d_s = attn .(d_attn - rowsum(d_attn . attn)) * scale formed in the tile
+//                            (softmax backward), d_q = d_s k, d_k = d_s^T q
+//
 // All reductions run in a fixed order that depends on N only: a batch equals its samples run one by one, bit for bit.
 // LDS images: [rows][64] tiles with the 16-B chunks of a row XOR-ed by (row & 15) (conflict-free ds_read_b128 over
 // 16 rows, conflict-free ds_read_b32 along a row); the [32][256] tile the same within each group of 16 chunks.
@@ -152,6 +161,7 @@ __device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __res
 }
 
 // out[j0 + j, d] = X[j, d] * acc * scale for the blocks of col_product (X = the resident key-side LDS image)
+template <bool RAW = false>   // RAW: out = acc (backward products), else out = X . acc * scale (relprop rule)
 __device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float* __restrict__ Kt, float* __restrict__ out,
                                              int64_t osn, int nj, int wave, int lr, int kh, int nblk, float scale) {
 #pragma unroll
@@ -162,7 +172,7 @@ __device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int j = (t >> 1) * 32 + crow(e, kh);
-        if (j < nj) out[(int64_t)j * osn + d] = (at64(Kt, j, d) * acc[s][e]) * scale;
+        if (j < nj) out[(int64_t)j * osn + d] = RAW ? acc[s][e] : (at64(Kt, j, d) * acc[s][e]) * scale;
       }
     }
   }
@@ -172,8 +182,11 @@ __device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float
 // AV rule.  R strided [B,H,N,64]; Z contiguous [B*H,N,64]; attn, cam_attn contiguous [B*H,N,N]; v, cam_v strided.
 // grid = BH * ngroups (bh fastest: with BH a multiple of 8 a (b,h)'s groups share an XCD)
 // ------------------------------------------------------------------------------------------------
+enum { RULE = 0, BWD = 1 };
+
+template <int MODE>
 __global__ __launch_bounds__(kT) void av_rule_kernel(
-    const float* __restrict__ R, Strided rs, const float* __restrict__ Z, const float* __restrict__ attn,
+    const float* __restrict__ R, Strided rs, const float* __restrict__ Z, Strided zs, const float* __restrict__ attn,
     const float* __restrict__ v, Strided vs, float* __restrict__ cam_attn, float* __restrict__ cam_v, Strided cs, int H,
     int N, int BH, int JG, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
   const float* r_bh = R + (int64_t)b * rs.sb + (int64_t)h * rs.sh;
-  const float* z_bh = Z + (int64_t)bh * N * 64;
+  const float* z_bh = (MODE == RULE) ? Z + (int64_t)b * zs.sb + (int64_t)h * zs.sh : nullptr;
   const float* a_bh = attn + (int64_t)bh * N * N + j0;
   float* ca_bh = cam_attn + (int64_t)bh * N * N + j0;
   const float* v_bh = v + (int64_t)b * vs.sb + (int64_t)h * vs.sh + (int64_t)j0 * vs.sn;
@@ -202,7 +215,8 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
     rr = zz = f32x4{0.f, 0.f, 0.f, 0.f};
     if (srow < rows_valid) {
       rr = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(i0 + srow) * rs.sn + (sc << 2));
-      zz = *reinterpret_cast<const f32x4_u*>(z_bh + (int64_t)(i0 + srow) * 64 + (sc << 2));
+      if constexpr (MODE == RULE)
+        zz = *reinterpret_cast<const f32x4_u*>(z_bh + (int64_t)(i0 + srow) * zs.sn + (sc << 2));
     }
   };
   fetch(0);
@@ -213,9 +227,11 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
     const int i0 = it * TI;
     __syncthreads();                       // the previous tile's readers are done (first trip: nothing to wait for)
     {
-      f32x4 s;
+      f32x4 s = rr;                                                  // BWD: the tile of d_out itself
+      if constexpr (MODE == RULE) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);     // rows beyond N: sd(0, 0) = 0
+        for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);     // rows beyond N: sd(0, 0) = 0
+      }
       *reinterpret_cast<f32x4*>(St + swz64(srow, sc)) = s;
       store_wide(Wt, wm, ta);
     }
@@ -237,20 +253,25 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int il = crow(e, kh);
-          if (i0 + il < N) ca_bh[(int64_t)(i0 + il) * N + jl] = (atw(Wt, il, jl) * gacc[e]) * scale;
+          if (i0 + il < N)
+            ca_bh[(int64_t)(i0 + il) * N + jl] = (MODE == RULE) ? (atw(Wt, il, jl) * gacc[e]) * scale : gacc[e];
         }
       }
     }
     col_product(accv, Wt, St, wave, lr, kh, 2 * njb);
   }
   float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
-  col_epilogue(accv, Vt, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
+  col_epilogue<MODE == BWD>(accv, Vt, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
 }
 
 // ------------------------------------------------------------------------------------------------
 // QK rule.  Rnn, Z contiguous [B*H,N,N]; q, k, cam_q, cam_k strided.  ngroups > 1: cam_q goes to `qpart`
 // [ngroups][B*H][N][64] unscaled (qk_finish_kernel folds the groups); cam_k of a group is complete.
 // ------------------------------------------------------------------------------------------------
+// MODE BWD: Rnn = d_attn, Z = attn; the S tile is the softmax backward d_s = attn .(d_attn - rowdot) * scale with
+// rowdot[i] = sum_j d_attn[i,j] attn[i,j] (single key group only: the row sum needs every key), outputs are the raw
+// products d_q = d_s k and d_k = d_s^T q.
+template <int MODE>
 __global__ __launch_bounds__(kT) void qk_rule_kernel(
     const float* __restrict__ Rnn, const float* __restrict__ Z, const float* __restrict__ q, Strided qs,
     const float* __restrict__ k, Strided ks, float* __restrict__ cam_q, Strided cqs, float* __restrict__ cam_k,
@@ -259,6 +280,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   float* Kt = smem;                    // [NJMAX][64]
   float* Qt = Kt + NJMAX * 64;         // [TI][64]
   float* Wt = Qt + TI * 64;            // [TI][256]: the S tile
+  float* Pt = Wt + TI * WLD;           // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -290,14 +312,44 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   for (int it = 0; it < ntiles; ++it) {
     const int i0 = it * TI;
     __syncthreads();
-    {
+    if constexpr (MODE == RULE) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) tr.v[r][e] = te_sd(tr.v[r][e], tz.v[r][e]);   // zero-filled slots: sd(0, 0) = 0
-      store_wide(Wt, wm, tr);
-      *reinterpret_cast<f32x4*>(Qt + swz64(srow, sc)) = qq;
+    } else {
+      // rowdot: per-float4 partials -> LDS, 16 lanes per row fold them in a fixed order
+      const int per_row = nj32 >> 2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (wm.row[r] >= 0) {
+          float p = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p = fmaf(tr.v[r][e], tz.v[r][e], p);
+          Pt[wm.row[r] * 64 + wm.c4[r]] = p;
+        }
+      __syncthreads();
+      {
+        float part = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (sc + 16 * m < per_row) part = part + Pt[srow * 64 + sc + 16 * m];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) part = part + __shfl_xor(part, off, 64);
+        __syncthreads();                       // every partial has been read
+        if (sc == 0) Pt[srow] = part;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (wm.row[r] >= 0) {
+          const float rd = Pt[wm.row[r]];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tr.v[r][e] = (tz.v[r][e] * (tr.v[r][e] - rd)) * scale;   // zero-filled: 0
+        }
     }
+    store_wide(Wt, wm, tr);
+    *reinterpret_cast<f32x4*>(Qt + swz64(srow, sc)) = qq;
     __syncthreads();
     if (it + 1 < ntiles) fetch(it + 1);
     {
@@ -329,7 +381,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
         if (i0 + il < N) {
           if (ngroups == 1) {
             cam_q[(int64_t)b * cqs.sb + (int64_t)h * cqs.sh + (int64_t)(i0 + il) * cqs.sn + dcol] =
-                (at64(Qt, il, dcol) * cq[r]) * scale;
+                (MODE == RULE) ? (at64(Qt, il, dcol) * cq[r]) * scale : cq[r];
           } else {
             qpart[(((int64_t)g * BH + bh) * N + i0 + il) * 64 + dcol] = cq[r];
           }
@@ -339,7 +391,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     col_product(acck, Wt, Qt, wave, lr, kh, 2 * njb);
   }
   float* o_bh = cam_k + (int64_t)b * cks.sb + (int64_t)h * cks.sh + (int64_t)j0 * cks.sn;
-  col_epilogue(acck, Kt, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
+  col_epilogue<MODE == BWD>(acck, Kt, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
 }
 
 // cam_q[i,d] = q[i,d] * (sum over groups of qpart[g][bh][i][d], in group order) * scale
@@ -364,11 +416,161 @@ __global__ __launch_bounds__(256) void qk_finish_kernel(const float* __restrict_
   *reinterpret_cast<f32x4_u*>(cam_q + (int64_t)b * cqs.sb + (int64_t)h * cqs.sh + (int64_t)i * cqs.sn + (c << 2)) = o;
 }
 
-constexpr size_t kLds = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD) * sizeof(float);   // 104 KB
+// ------------------------------------------------------------------------------------------------
+// Producer: attention forward of one (b, h) on the fused qkv activation [B,N,3C] ('b n (qkv h d)', ViT_LRP.py:135):
+//   z_qk [BH,N,N] = q k^T (unscaled);  attn [BH,N,N] = softmax(z_qk * scale);  out [B,N,C] ('b n (h d)') = attn v
+// N <= 224: k and v (2 x 56 KB) stay in LDS next to the q tile and the [32][256] score tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int NJF = 224;
+__global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ zqk,
+                                                      float* __restrict__ attn, float* __restrict__ out, int H, int N,
+                                                      float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Kt = smem;                    // [NJF][64]
+  float* Vt = Kt + NJF * 64;           // [NJF][64]
+  float* Qt = Vt + NJF * 64;           // [TI][64]
+  float* Wt = Qt + TI * 64;            // [TI][256]: scaled scores, then probabilities
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int C = H * 64;
+  const int64_t sn = 3 * (int64_t)C;
+  const int nj = N, nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  const float* q_bh = qkv + (int64_t)b * N * sn + h * 64;
+  const float* k_bh = q_bh + C;
+  const float* v_bh = q_bh + 2 * C;
+  float* z_bh = zqk + (int64_t)bh * N * N;
+  float* a_bh = attn + (int64_t)bh * N * N;
+  float* o_bh = out + (int64_t)b * N * C + h * 64;
+  const int ntiles = (N + TI - 1) / TI;
+  const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
+  stage_keys(Kt, k_bh, sn, nj, nj32);
+  stage_keys(Vt, v_bh, sn, nj, nj32);
+  f32x4 qq = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int it) __attribute__((always_inline)) {
+    const int i0 = it * TI;
+    qq = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i0 + srow < N) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * sn + (sc << 2));
+  };
+  fetch(0);
+  const int ib = wave >> 2, db = wave & 3, l15 = lane & 15, kq = lane >> 4;
+  for (int it = 0; it < ntiles; ++it) {
+    const int i0 = it * TI;
+    __syncthreads();                           // previous tile's readers of Qt / Wt are done
+    *reinterpret_cast<f32x4*>(Qt + swz64(srow, sc)) = qq;
+    __syncthreads();
+    if (it + 1 < ntiles) fetch(it + 1);
+    if (wave < njb) {
+      // scores of key block `wave`: z = q k^T
+      f32x16 z;
+      zero16(z);
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Qt + swz64(lr, kg * 2 + kh));
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(Kt + swz64(wave * 32 + lr, kg * 2 + kh));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z = TE_MFMA32(a[j], bq[j], z);
+      }
+      const int jl = wave * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int il = crow(e, kh);
+        if (jl < nj && i0 + il < N) z_bh[(int64_t)(i0 + il) * N + jl] = z[e];
+        Wt[swzw(il, jl >> 2) + (jl & 3)] = z[e] * scale;       // 'dots = einsum(...) * self.scale' (ViT_LRP.py:139)
+      }
+    }
+    __syncthreads();
+    {
+      // row softmax over the nj valid columns: 16 lanes per row, float4 chunks sc + 16 m
+      f32x4 x[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = sc + 16 * m;
+        x[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (c * 4 < nj32) {
+          x[m] = *reinterpret_cast<const f32x4*>(Wt + swzw(srow, c));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (c * 4 + e >= nj) x[m][e] = -INFINITY;
+            mx = fmaxf(mx, x[m][e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float sum = 0.0f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[m][e] = expf(x[m][e] - mx);                    // exp(-inf) = 0 for the padded columns
+          sum = sum + x[m][e];
+        }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) sum = sum + __shfl_xor(sum, off, 64);
+      const bool row_ok = i0 + srow < N;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int c = sc + 16 * m;
+        if (c * 4 < nj32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[m][e] = x[m][e] / sum;
+          *reinterpret_cast<f32x4*>(Wt + swzw(srow, c)) = x[m];
+          if (row_ok) {
+            float* dst = a_bh + (int64_t)(i0 + srow) * N;
+            if (c * 4 + 3 < nj) {
+              *reinterpret_cast<f32x4_u*>(dst + c * 4) = x[m];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (c * 4 + e < nj) dst[c * 4 + e] = x[m][e];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // out block (ib, db) = P[16 x keys] v[keys x 16]
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      const int arow = ib * 16 + l15, dcol = db * 16 + l15;
+#pragma unroll 2
+      for (int kp = 0; kp < (nj32 >> 5); ++kp) {
+        f32x4 a[2];
+        float bv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kg = kp * 2 + u;
+          a[u] = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kg * 4 + kq));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[u][j] = at64(Vt, kg * 16 + kq * 4 + j, dcol);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o = TE_MFMA16(a[u][j], bv[u][j], o);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = ib * 16 + kq * 4 + r;
+        if (i0 + il < N) o_bh[(int64_t)(i0 + il) * C + dcol] = o[r];
+      }
+    }
+  }
+}
+
+constexpr size_t kLds = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD) * sizeof(float);            // 104 KB
+constexpr size_t kLdsBwd = kLds + (size_t)TI * 64 * sizeof(float);                            // + rowdot scratch
+constexpr size_t kLdsFwd = (size_t)(2 * NJF * 64 + TI * 64 + TI * WLD) * sizeof(float);        // 152 KB
 
 inline void groups_for(int64_t N, int& ng, int& jg) {
   ng = (int)((N + NJMAX - 1) / NJMAX);
   jg = (int)(((N + ng - 1) / ng + 31) & ~(int64_t)31);      // equal groups, rounded up to whole 32-key blocks
+}
+
+template <typename K>
+inline void allow_lds(K kern, size_t bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 }  // namespace
@@ -388,28 +590,17 @@ bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   return D == 64 && N >= 1 && N <= 4096 && B * H * ng <= 0x7fffffff;
 }
 
-// extra workspace (floats) of the QK rule beyond Z: the per-group cam_q partials
-size_t qk_partial_floats(int64_t B, int64_t H, int64_t N) {
-  int ng, jg;
-  groups_for(N, ng, jg);
-  return ng > 1 ? (size_t)ng * B * H * N * 64 : 0;
-}
-
 int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn, const float* v, int64_t v_sb,
-              int64_t v_sh, int64_t v_sn, const float* Z, float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh,
-              int64_t cv_sn, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream) {
+              int64_t v_sh, int64_t v_sn, const float* Z, int64_t z_sb, int64_t z_sh, int64_t z_sn, float* cam_attn,
+              float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N, float scale,
+              hipStream_t stream) {
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
-  static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(av_rule_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kLds);
-    return true;
-  }();
-  (void)once;
-  av_rule_kernel<<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(
-      R, Strided{r_sb, r_sh, r_sn}, Z, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v, Strided{cv_sb, cv_sh, cv_sn},
-      (int)H, (int)N, BH, jg, scale);
+  allow_lds(av_rule_kernel<RULE>, kLds);
+  av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(
+      R, Strided{r_sb, r_sh, r_sn}, Z, Strided{z_sb, z_sh, z_sn}, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v,
+      Strided{cv_sb, cv_sh, cv_sn}, (int)H, (int)N, BH, jg, scale);
   return TE_OK;
 }
 
@@ -420,15 +611,11 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
-  static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qk_rule_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)kLds);
-    return true;
-  }();
-  (void)once;
+  allow_lds(qk_rule_kernel<RULE>, kLds);
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
-  qk_rule_kernel<<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k, cks,
-                                                                        qpart, (int)H, (int)N, BH, jg, ng, scale);
+  qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
+                                                                              cks, qpart, (int)H, (int)N, BH, jg, ng,
+                                                                              scale);
   if (ng > 1) {
     const int64_t n4 = (int64_t)BH * N * 16;
     qk_finish_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(qpart, q, qs, cam_q, cqs, (int)H,
@@ -438,3 +625,53 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
 }
 
 }  // namespace te_attn_rules
+
+// ================================================================================================
+// C ABI of the producers
+// ================================================================================================
+using te_attn_rules::Strided;
+
+extern "C" int te_attention_forward_supported(int64_t N, int64_t D) {
+  return (D == 64 && N >= 1 && N <= te_attn_rules::NJF) ? 1 : 0;
+}
+
+extern "C" int te_attention_forward_f32(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H,
+                                        int64_t N, int64_t D, float scale, te_stream_t stream_) {
+  if (!qkv || !z_qk || !attn || !out || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
+  if (!te_attention_forward_supported(N, D) || B * H > 0x7fffffff) return TE_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  te_attn_rules::allow_lds(te_attn_rules::attn_fwd_kernel, te_attn_rules::kLdsFwd);
+  te_attn_rules::attn_fwd_kernel<<<dim3((unsigned)(B * H)), dim3(te_attn_rules::kT), te_attn_rules::kLdsFwd, stream>>>(
+      qkv, z_qk, attn, out, (int)H, (int)N, scale);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn,
+                                         float* d_qkv, int64_t B, int64_t H, int64_t N, int64_t D, float scale,
+                                         int need_qk, te_stream_t stream_) {
+  if (!d_out || !qkv || !attn || !d_attn || !d_qkv || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
+  if (!te_attention_forward_supported(N, D) || B * H > 0x7fffffff) return TE_ERR_UNSUPPORTED;
+  using namespace te_attn_rules;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t C = H * 64;
+  const int BH = (int)(B * H);
+  const Strided heads{N * C, 64, C};            // [B,N,C] seen as [B,H,N,64]
+  const Strided fused{N * 3 * C, 64, 3 * C};    // one of q / k / v inside [B,N,3C]
+  int ng, jg;
+  groups_for(N, ng, jg);                        // N <= 224: one group
+  // d_attn = d_out v^T ; d_v = attn^T d_out
+  allow_lds(av_rule_kernel<BWD>, kLds);
+  av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLds, stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
+                                                                      qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
+                                                                      (int)H, (int)N, BH, jg, 1.0f);
+  if (need_qk) {
+    // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q
+    allow_lds(qk_rule_kernel<BWD>, kLdsBwd);
+    qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsBwd, stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
+                                                                           d_qkv, fused, d_qkv + C, fused, nullptr,
+                                                                           (int)H, (int)N, BH, jg, 1, scale);
+  }
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}

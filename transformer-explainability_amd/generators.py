@@ -30,6 +30,20 @@ def _one_hot(output: torch.Tensor, index) -> torch.Tensor:
 
 
 def _attention_gradients(loss, attn_modules):
+    """Attention gradients of the listed modules (lowest block first), nothing else: no weight gradients, nothing below
+    the lowest listed block."""
+    anchors = [getattr(m, "_fused_anchor", None) for m in attn_modules]
+    if anchors and all(a is not None for a in anchors):
+        # producer kernels (vit._FusedAttention): the gradient w.r.t. the probabilities is formed inside the block's
+        # own backward and handed to save_attn_gradients; drive autograd down to the lowest block's qkv activation and
+        # tell that block that nothing consumes its d_qkv
+        lowest = attn_modules[0]
+        lowest._fused_stop_backward = True
+        try:
+            torch.autograd.grad(loss, [anchors[0]], retain_graph=False, allow_unused=True)
+        finally:
+            lowest._fused_stop_backward = False
+        return
     attns = [m.get_attn() for m in attn_modules]
     grads = torch.autograd.grad(loss, attns, retain_graph=False, allow_unused=False)
     for m, g in zip(attn_modules, grads):

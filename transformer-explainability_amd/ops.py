@@ -195,7 +195,14 @@ def matmul_relprop_av(R: Tensor, attn: Tensor, v: Tensor, out_scale: float = 1.0
     [B,H,N,D] view, e.g. a slice of the 'b n (qkv h d)' relevance buffer).  z (optional) = attn @ v as the
     forward pass computed it (self.Y of the product module)."""
     B, H, N, D = v.shape
-    zc = _cached_z(z, (B, H, N, D))
+    zc = None
+    z_str = (H * N * D, N * D, D)
+    if z is not None and USE_FORWARD_PRODUCTS and tuple(z.shape) == (B, H, N, D):
+        zd = _prep(z.detach())
+        if zd.stride(-1) == 1 and min(zd.stride()[:3]) > 0:
+            zc, z_str = zd, tuple(zd.stride()[:3])        # read in place (e.g. a view of the 'b n (h d)' activation)
+        else:
+            zc = zd.contiguous()
     R, r_sb, r_sh, r_sn = _bhnd(R)
     v, v_sb, v_sh, v_sn = _bhnd(v)
     attn = _c(attn)
@@ -207,10 +214,15 @@ def matmul_relprop_av(R: Tensor, attn: Tensor, v: Tensor, out_scale: float = 1.0
     with _on_device(attn) as lib, _timed("attention_av_rule", 4.0 * B * H * N * N * D,
                                          4.0 * B * H * (2 * N * N + 5 * N * D)):
         ws = _ws(lib.te_matmul_relprop_av_workspace_bytes(B, H, N, D), attn)
-        _lib.check(lib.te_matmul_relprop_av_fwd_f32(
-            _ptr(R), r_sb, r_sh, r_sn, _ptr(attn), _ptr(v), v_sb, v_sh, v_sn, _ptr(zc), _ptr(cam_attn),
-            _ptr(cam_v), cv_sb, cv_sh, cv_sn, B, H, N, D, float(out_scale), _variant(variant),
-            _ptr(ws), ws.numel(), _stream(attn)), "te_matmul_relprop_av_fwd_f32")
+        args = (_ptr(cam_attn), _ptr(cam_v), cv_sb, cv_sh, cv_sn, B, H, N, D, float(out_scale), _variant(variant),
+                _ptr(ws), ws.numel(), _stream(attn))
+        rc = lib.te_matmul_relprop_av_fwdz_f32(_ptr(R), r_sb, r_sh, r_sn, _ptr(attn), _ptr(v), v_sb, v_sh, v_sn,
+                                               _ptr(zc), z_str[0], z_str[1], z_str[2], *args)
+        if rc == _lib.TE_ERR_UNSUPPORTED and zc is not None and not zc.is_contiguous():
+            zc = zc.contiguous()       # kernels that read Z as a contiguous [B,H,N,D] tensor
+            rc = lib.te_matmul_relprop_av_fwd_f32(_ptr(R), r_sb, r_sh, r_sn, _ptr(attn), _ptr(v), v_sb, v_sh, v_sn,
+                                                  _ptr(zc), *args)
+        _lib.check(rc, "te_matmul_relprop_av_fwdz_f32")
     return cam_attn, cam_v
 
 
@@ -239,6 +251,50 @@ def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
             B, H, N, D, float(out_scale), _variant(variant), _ptr(ws), ws.numel(), _stream(R)),
             "te_matmul_relprop_qk_fwd_f32")
     return cam_q, cam_k
+
+
+# ---------------------------------------------------------------------------------------- 8f.1 producers
+# Attention blocks run their forward (and attention-gradient backward) on the hand-written producer kernels where
+# te_attention_forward_supported(N, D) (head dim 64, N <= 224); stock PyTorch otherwise.  bench.py --producers fused.
+USE_FUSED_PRODUCERS = False
+
+
+def attention_forward_supported(N: int, D: int) -> bool:
+    return bool(_lib.load().te_attention_forward_supported(int(N), int(D)))
+
+
+def attention_forward(qkv: Tensor, num_heads: int, scale: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """qkv [B,N,3C] ('b n (qkv h d)') -> (out [B,N,C] = softmax(q k^T * scale) v as 'b n (h d)', attn [B,H,N,N],
+    z_qk [B,H,N,N] = the unscaled q k^T).  ViT_LRP.py:132-152 without the q/k/v, scale, softmax and transpose passes."""
+    qkv = _c(qkv)
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    H, D = num_heads, C // num_heads
+    out = torch.empty((B, N, C), dtype=torch.float32, device=qkv.device)
+    attn = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
+    zqk = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
+    with _on_device(qkv) as lib, _timed("attention_forward", 4.0 * B * H * N * N * D, 4.0 * B * (2 * H * N * N + 4 * N * C)):
+        _lib.check(lib.te_attention_forward_f32(_ptr(qkv), _ptr(zqk), _ptr(attn), _ptr(out), B, H, N, D, float(scale),
+                                                _stream(qkv)), "te_attention_forward_f32")
+    return out, attn, zqk
+
+
+def attention_backward(d_out: Tensor, qkv: Tensor, attn: Tensor, num_heads: int, scale: float,
+                       need_qk: bool = True) -> Tuple[Tensor, Tensor]:
+    """Gradient of attention_forward: d_out [B,N,C] -> (d_attn [B,H,N,N], d_qkv [B,N,3C]).  need_qk=False leaves the
+    q / k thirds of d_qkv zero (nothing below consumes them)."""
+    d_out, qkv, attn = _c(d_out), _c(qkv), _c(attn)
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    H, D = num_heads, C // num_heads
+    d_attn = torch.empty_like(attn)
+    d_qkv = torch.empty_like(qkv) if need_qk else torch.zeros_like(qkv)
+    with _on_device(qkv) as lib, _timed("attention_backward", (8.0 if need_qk else 4.0) * B * H * N * N * D,
+                                        4.0 * B * ((4 if need_qk else 2) * H * N * N + 8 * N * C)):
+        _lib.check(lib.te_attention_backward_f32(_ptr(d_out), _ptr(qkv), _ptr(attn), _ptr(d_attn), _ptr(d_qkv), B, H, N,
+                                                 D, float(scale), int(bool(need_qk)), _stream(qkv)),
+                   "te_attention_backward_f32")
+    return d_attn, d_qkv
 
 
 # ---------------------------------------------------------------------------------------- a5

@@ -65,6 +65,34 @@ def split_qkv(qkv, num_heads):
     return _SplitQKV.apply(qkv, num_heads)
 
 
+class _FusedAttention(torch.autograd.Function):
+    """the attention block of ViT_LRP.py:132-152 on the hand-written producer kernels
+    (te_attention_forward_f32 / te_attention_backward_f32) instead of ~10 stock launches per direction.
+
+    forward : qkv [B,N,3C] -> out [B,N,C]; the probabilities and the unscaled scores (the tensors the relprop rules and
+              the accessors read) come back as non-differentiable by-products.
+    backward: computes d_attn -- the attention gradient the explanation needs -- and hands it to the module
+              (save_attn_gradients, what the reference's register_hook does, ViT_LRP.py:144-145), then d_qkv for the
+              layers below; a module whose ``_fused_stop_backward`` is set is the lowest block whose gradient is
+              wanted: nothing consumes d_qkv there, so only d_attn is formed."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads, scale, module):
+        out, attn, zqk = ops.attention_forward(qkv, num_heads, scale)
+        ctx.save_for_backward(qkv, attn)
+        ctx.num_heads, ctx.scale, ctx.module = num_heads, scale, module
+        ctx.mark_non_differentiable(attn, zqk)
+        return out, attn, zqk
+
+    @staticmethod
+    def backward(ctx, d_out, _d_attn_unused, _d_zqk_unused):
+        qkv, attn = ctx.saved_tensors
+        stop = bool(getattr(ctx.module, "_fused_stop_backward", False))
+        d_attn, d_qkv = ops.attention_backward(d_out, qkv, attn, ctx.num_heads, ctx.scale, need_qk=not stop)
+        ctx.module.save_attn_gradients(d_attn)
+        return (None if stop else d_qkv), None, None, None
+
+
 def make_vit_module(L):
     """Build the model classes over a rule namespace ``L`` (rules for 'ours', rules_lrp for 'lrp')."""
 
@@ -118,6 +146,10 @@ def make_vit_module(L):
         def forward(self, x):
             B, N, C = x.shape
             H = self.num_heads
+            self._fused_anchor = None
+            if (ops.USE_FUSED_PRODUCERS and x.is_cuda and x.dtype == torch.float32 and not self.training
+                    and ops.attention_forward_supported(N, C // H)):
+                return self._forward_fused(x)
             q, k, v = split_qkv(self.qkv(x), H)                                 # 'b n (qkv h d) -> qkv b h n d'
             self.save_v(v)
             attn = self.attn_drop(self.softmax(self.matmul1([q, k]) * self.scale))
@@ -125,6 +157,24 @@ def make_vit_module(L):
             if attn.requires_grad:
                 attn.register_hook(self.save_attn_gradients)
             out = self.matmul2([attn, v]).permute(0, 2, 1, 3).reshape(B, N, C)  # 'b h n d -> b n (h d)'
+            return self.proj_drop(self.proj(out))
+
+        def _forward_fused(self, x):
+            """ViT_LRP.py:132-152 on the producer kernels.  q / k / v are never copied out of the fused activation: the
+            rule modules' caches (matmul1.X / .Y, matmul2.X / .Y) are strided views of it and of the 'b n (h d)'
+            output, which the relprop kernels read in place."""
+            B, N, C = x.shape
+            H, D = self.num_heads, C // self.num_heads
+            qkv = self.qkv(x)
+            out, attn, zqk = _FusedAttention.apply(qkv, H, self.scale, self)
+            self._fused_anchor = qkv if qkv.requires_grad else None
+            q, k, v = qkv.detach().view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+            self.save_v(v)
+            self.save_attn(attn)
+            zav = out.detach().view(B, N, H, D).permute(0, 2, 1, 3)
+            for mod, X, Y in ((self.matmul1, [q, k], zqk), (self.matmul2, [attn, v], zav)):
+                mod.X, mod.Y = X, Y
+                mod._y_version, mod._w_version = Y._version, (None, None)
             return self.proj_drop(self.proj(out))
 
         def relprop(self, cam, **kwargs):
