@@ -35,6 +35,13 @@ def main():
     Rnn = torch.randn(B, H, N, N, device=d) * 0.01
     av = t(lambda: ops.matmul_relprop_av(R, attn, v, out_scale=0.5, z=zav))
     qk = t(lambda: ops.matmul_relprop_qk(Rnn, q, k, out_scale=0.5, z=zqk))
+    if len(sys.argv) > 5 and sys.argv[5] == "producers" and ops.attention_forward_supported(N, D):
+        qkv = torch.randn(B, N, 3 * H * D, device=d)
+        g = torch.randn(B, N, H * D, device=d)
+        _, attn_p, _ = ops.attention_forward(qkv, H, D ** -0.5)
+        fw = t(lambda: ops.attention_forward(qkv, H, D ** -0.5))
+        bw = t(lambda: ops.attention_backward(g, qkv, attn_p, H, D ** -0.5))
+        print(f"B={B} H={H} N={N}: producer forward {fw:7.1f} us   backward {bw:7.1f} us")
     nn = B * H * N * N * 4 / 1e6
     print(f"B={B} H={H} N={N}: AV rule {av:7.1f} us   QK rule {qk:7.1f} us   (one [B,H,N,N] tensor = {nn:.0f} MB)")
 

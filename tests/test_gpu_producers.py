@@ -46,8 +46,9 @@ def test_attention_forward_producer(B, H, N):
     spiky[:, 0, :H * D] *= 30.0
     s_out, s_attn, _ = ops.attention_forward(spiky, H, scale)
     rs_out, rs_attn, _ = _stock(spiky, H, scale)
-    check(f"producer.fwd.spiky.attn({B},{H},{N})", s_attn, rs_attn, 3e-6)
-    check(f"producer.fwd.spiky.out({B},{H},{N})", s_out, rs_out, 3e-6)
+    # (scores up to a few hundred: one fp32 ulp of the scaled score is ~3e-5, and exp() turns it into a relative error)
+    check(f"producer.fwd.spiky.attn({B},{H},{N})", s_attn, rs_attn, 3e-5)
+    check(f"producer.fwd.spiky.out({B},{H},{N})", s_out, rs_out, 3e-5)
     one = ops.attention_forward(qkv[:1].contiguous(), H, scale)
     assert torch.equal(one[0], out[:1]) and torch.equal(one[1], attn[:1]) and torch.equal(one[2], zqk[:1])
 

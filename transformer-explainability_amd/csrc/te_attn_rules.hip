@@ -74,6 +74,13 @@ __device__ __forceinline__ float at64(const float* __restrict__ T, int row, int 
 __device__ __forceinline__ float atw(const float* __restrict__ T, int row, int x) {
   return T[swzw(row, x >> 2) + (x & 3)];
 }
+// TRANSPOSED images for the column-side products ([x][32 query rows], 128-B rows, K = query row contiguous): chunk
+// XOR-ed by ((x >> 1) ^ (x >> 4)) & 7 -- conflict-free ds_read_b128 over the 16 rows of a lane group (te_linear.hip's
+// scheme), 4-way on the scalar transposing stores (cheaper than the store's own issue time)
+__device__ __forceinline__ int swzT(int x, int chunk) { return x * TI + ((chunk ^ (((x >> 1) ^ (x >> 4)) & 7)) << 2); }
+__device__ __forceinline__ float atT(const float* __restrict__ T, int x, int i) {
+  return T[swzT(x, i >> 2) + (i & 3)];
+}
 __device__ __forceinline__ int crow(int e, int kh) { return (e & 3) + 8 * (e >> 2) + 4 * kh; }
 
 __device__ __forceinline__ void zero16(f32x16& a) {
@@ -129,6 +136,21 @@ __device__ __forceinline__ void store_wide(float* __restrict__ lds, const WideMa
     if (m.row[r] >= 0) *reinterpret_cast<f32x4*>(lds + swzw(m.row[r], m.c4[r])) = t.v[r];
 }
 
+// the same tile transposed: element (row i, column x) -> T[x][i]
+__device__ __forceinline__ void store_wide_T(float* __restrict__ lds, const WideMap& m, const WideTile& t) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m.row[r] >= 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[swzT((m.c4[r] << 2) + e, m.row[r] >> 2) + (m.row[r] & 3)] = t.v[r][e];
+    }
+}
+// one float4 (row i, columns 4 c .. 4 c + 3) of a [TI][64] tile, transposed
+__device__ __forceinline__ void store_small_T(float* __restrict__ lds, int i, int c, f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lds[swzT((c << 2) + e, i >> 2) + (i & 3)] = v[e];
+}
+
 // key-side operand (v or k) of this group: rows [j0, j0 + nj) -> LDS [nj32][64], rows >= nj zero
 __device__ __forceinline__ void stage_keys(float* __restrict__ Kt, const float* __restrict__ src, int64_t sn, int nj,
                                            int nj32) {
@@ -140,22 +162,26 @@ __device__ __forceinline__ void stage_keys(float* __restrict__ Kt, const float* 
   }
 }
 
-// column-side product of one row tile:  acc[(jb, db)] += W^T[keys x 32] Yt[32 x 64], 32x32 blocks t = 2 jb + db,
+// column-side product of one row tile:  acc[(jb, db)] += W^T[keys x 32] Y[32 x 64] from the TRANSPOSED images
+// WtT [keys][32] and YtT [64][32] (both K-contiguous: one ds_read_b128 feeds four MFMAs), 32x32 blocks t = 2 jb + db,
 // wave w owns t = w and t = w + 8
-__device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __restrict__ Wt, const float* __restrict__ Yt,
+__device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __restrict__ WtT, const float* __restrict__ YtT,
                                             int wave, int lr, int kh, int nblk) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int t = wave + s * kWaves;
     if (t < nblk) {
       const int jx = (t >> 1) * 32 + lr, dx = (t & 1) * 32 + lr;
+      f32x4 a[TI / 8], bq[TI / 8];
+#pragma unroll
+      for (int kg = 0; kg < TI / 8; ++kg) {
+        a[kg] = *reinterpret_cast<const f32x4*>(WtT + swzT(jx, kg * 2 + kh));
+        bq[kg] = *reinterpret_cast<const f32x4*>(YtT + swzT(dx, kg * 2 + kh));
+      }
 #pragma unroll
       for (int kg = 0; kg < TI / 8; ++kg)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = kg * 8 + kh * 4 + j;
-          acc[s] = TE_MFMA32(atw(Wt, k, jx), at64(Yt, k, dx), acc[s]);
-        }
+        for (int j = 0; j < 4; ++j) acc[s] = TE_MFMA32(a[kg][j], bq[kg][j], acc[s]);
     }
   }
 }
@@ -191,8 +217,9 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
     int N, int BH, int JG, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vt = smem;                    // [NJMAX][64]
-  float* St = Vt + NJMAX * 64;         // [TI][64]
-  float* Wt = St + TI * 64;            // [TI][256]: the attn tile
+  float* St = Vt + NJMAX * 64;         // [TI][64]   S (row-side A operand, K = d contiguous)
+  float* StT = St + TI * 64;           // [64][TI]   S transposed (column-side B operand, K = query row contiguous)
+  float* WtT = StT + 64 * TI;          // [256][TI]  the attn tile, transposed (column-side A operand)
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -233,7 +260,8 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
         for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);     // rows beyond N: sd(0, 0) = 0
       }
       *reinterpret_cast<f32x4*>(St + swz64(srow, sc)) = s;
-      store_wide(Wt, wm, ta);
+      store_small_T(StT, srow, sc, s);
+      store_wide_T(WtT, wm, ta);
     }
     __syncthreads();
     if (it + 1 < ntiles) fetch(it + 1);
@@ -254,11 +282,11 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
         for (int e = 0; e < 16; ++e) {
           const int il = crow(e, kh);
           if (i0 + il < N)
-            ca_bh[(int64_t)(i0 + il) * N + jl] = (MODE == RULE) ? (atw(Wt, il, jl) * gacc[e]) * scale : gacc[e];
+            ca_bh[(int64_t)(i0 + il) * N + jl] = (MODE == RULE) ? (atT(WtT, jl, il) * gacc[e]) * scale : gacc[e];
         }
       }
     }
-    col_product(accv, Wt, St, wave, lr, kh, 2 * njb);
+    col_product(accv, WtT, StT, wave, lr, kh, 2 * njb);
   }
   float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
   col_epilogue<MODE == BWD>(accv, Vt, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
@@ -278,9 +306,10 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     Strided cks, float* __restrict__ qpart, int H, int N, int BH, int JG, int ngroups, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Kt = smem;                    // [NJMAX][64]
-  float* Qt = Kt + NJMAX * 64;         // [TI][64]
-  float* Wt = Qt + TI * 64;            // [TI][256]: the S tile
-  float* Pt = Wt + TI * WLD;           // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
+  float* QtT = Kt + NJMAX * 64;        // [64][TI]   q tile transposed (column-side B operand)
+  float* Wt = QtT + 64 * TI;           // [TI][256]  the S tile (row-side A operand, K = key contiguous)
+  float* WtT = Wt + TI * WLD;          // [256][TI]  the S tile transposed (column-side A operand)
+  float* Pt = WtT + NJMAX * TI;        // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -349,7 +378,8 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
         }
     }
     store_wide(Wt, wm, tr);
-    *reinterpret_cast<f32x4*>(Qt + swz64(srow, sc)) = qq;
+    store_wide_T(WtT, wm, tr);
+    store_small_T(QtT, srow, sc, qq);
     __syncthreads();
     if (it + 1 < ntiles) fetch(it + 1);
     {
@@ -381,14 +411,14 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
         if (i0 + il < N) {
           if (ngroups == 1) {
             cam_q[(int64_t)b * cqs.sb + (int64_t)h * cqs.sh + (int64_t)(i0 + il) * cqs.sn + dcol] =
-                (MODE == RULE) ? (at64(Qt, il, dcol) * cq[r]) * scale : cq[r];
+                (MODE == RULE) ? (atT(QtT, dcol, il) * cq[r]) * scale : cq[r];
           } else {
             qpart[(((int64_t)g * BH + bh) * N + i0 + il) * 64 + dcol] = cq[r];
           }
         }
       }
     }
-    col_product(acck, Wt, Qt, wave, lr, kh, 2 * njb);
+    col_product(acck, WtT, QtT, wave, lr, kh, 2 * njb);
   }
   float* o_bh = cam_k + (int64_t)b * cks.sb + (int64_t)h * cks.sh + (int64_t)j0 * cks.sn;
   col_epilogue<MODE == BWD>(acck, Kt, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
@@ -559,8 +589,9 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
   }
 }
 
-constexpr size_t kLds = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD) * sizeof(float);            // 104 KB
-constexpr size_t kLdsBwd = kLds + (size_t)TI * 64 * sizeof(float);                            // + rowdot scratch
+constexpr size_t kLdsAv = (size_t)(NJMAX * 64 + 2 * TI * 64 + NJMAX * TI) * sizeof(float);                // 112 KB
+constexpr size_t kLdsQk = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD + NJMAX * TI) * sizeof(float);        // 136 KB
+constexpr size_t kLdsQkBwd = kLdsQk + (size_t)TI * 64 * sizeof(float);                                    // + rowdot scratch
 constexpr size_t kLdsFwd = (size_t)(2 * NJF * 64 + TI * 64 + TI * WLD) * sizeof(float);        // 152 KB
 
 inline void groups_for(int64_t N, int& ng, int& jg) {
@@ -597,8 +628,8 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
-  allow_lds(av_rule_kernel<RULE>, kLds);
-  av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(
+  allow_lds(av_rule_kernel<RULE>, kLdsAv);
+  av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLdsAv, stream>>>(
       R, Strided{r_sb, r_sh, r_sn}, Z, Strided{z_sb, z_sh, z_sn}, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v,
       Strided{cv_sb, cv_sh, cv_sn}, (int)H, (int)N, BH, jg, scale);
   return TE_OK;
@@ -611,9 +642,9 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
-  allow_lds(qk_rule_kernel<RULE>, kLds);
+  allow_lds(qk_rule_kernel<RULE>, kLdsQk);
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
-  qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLds, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
+  qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLdsQk, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
                                                                               cks, qpart, (int)H, (int)N, BH, jg, ng,
                                                                               scale);
   if (ng > 1) {
@@ -661,14 +692,14 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
   int ng, jg;
   groups_for(N, ng, jg);                        // N <= 224: one group
   // d_attn = d_out v^T ; d_v = attn^T d_out
-  allow_lds(av_rule_kernel<BWD>, kLds);
-  av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLds, stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
+  allow_lds(av_rule_kernel<BWD>, kLdsAv);
+  av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsAv, stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
                                                                       qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
                                                                       (int)H, (int)N, BH, jg, 1.0f);
   if (need_qk) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q
-    allow_lds(qk_rule_kernel<BWD>, kLdsBwd);
-    qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsBwd, stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
+    allow_lds(qk_rule_kernel<BWD>, kLdsQkBwd);
+    qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsQkBwd, stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
                                                                            d_qkv, fused, d_qkv + C, fused, nullptr,
                                                                            (int)H, (int)N, BH, jg, 1, scale);
   }
