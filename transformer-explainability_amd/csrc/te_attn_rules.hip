@@ -162,6 +162,60 @@ __device__ __forceinline__ void stage_keys(float* __restrict__ Kt, const float* 
   }
 }
 
+// row-side product with a 32x32 output block:  acc += A[32 x 64] B[32 x 64]^T, both K-contiguous [rows][64] images.
+// All sixteen fragments are requested before the first MFMA (one LDS round trip per product instead of one per
+// four MFMAs -- hipcc otherwise waits lgkmcnt(0) in front of every group).
+__device__ __forceinline__ void row_product32(f32x16& acc, const float* __restrict__ At, int arow,
+                                              const float* __restrict__ Bt, int brow, int kh) {
+  f32x4 a[8], bq[8];
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) {
+    a[kg] = *reinterpret_cast<const f32x4*>(At + swz64(arow, kg * 2 + kh));
+    bq[kg] = *reinterpret_cast<const f32x4*>(Bt + swz64(brow, kg * 2 + kh));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = TE_MFMA32(a[kg][j], bq[kg][j], acc);
+}
+
+// row-side product with a 16x16 output block over K = nj32 keys:  acc += W[16 x keys] X[keys x 16], W = the
+// [TI][256] tile (K = key contiguous), XtT = the key-side operand TRANSPOSED [64][256] (K = key contiguous), both
+// read with ds_read_b128; software-pipelined two 16-key groups at a time (the next pair's fragments are requested
+// before the current pair's eight MFMAs).  nj32 is a multiple of 32.
+__device__ __forceinline__ void row_product16(f32x4& acc, const float* __restrict__ Wt, int arow,
+                                              const float* __restrict__ XtT, int dcol, int kq, int nj32) {
+  const int np = nj32 >> 5;
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kq)), a1 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, 4 + kq));
+  f32x4 b0 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, kq)), b1 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, 4 + kq));
+  for (int kp = 0; kp < np; ++kp) {
+    const int c = (kp + 1 < np) ? (kp + 1) * 8 + kq : kq;      // (last trip: a harmless re-read)
+    const f32x4 na0 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, c)), na1 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, c + 4));
+    const f32x4 nb0 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, c)), nb1 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, c + 4));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = TE_MFMA16(a0[j], b0[j], acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = TE_MFMA16(a1[j], b1[j], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
+  }
+}
+
+// key-side operand transposed: rows [j0, j0 + nj) of src [.,64] -> LDS [64][256] (element (j, d) at (d, j)), keys
+// >= nj zero
+__device__ __forceinline__ void stage_keys_T(float* __restrict__ KtT, const float* __restrict__ src, int64_t sn, int nj,
+                                             int nj32) {
+  for (int idx = threadIdx.x; idx < nj32 * 16; idx += kT) {
+    const int row = idx >> 4, c = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nj) v = *reinterpret_cast<const f32x4_u*>(src + (int64_t)row * sn + (c << 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) KtT[swzw((c << 2) + e, row >> 2) + (row & 3)] = v[e];
+  }
+}
+
 // column-side product of one row tile:  acc[(jb, db)] += W^T[keys x 32] Y[32 x 64] from the TRANSPOSED images
 // WtT [keys][32] and YtT [64][32] (both K-contiguous: one ds_read_b128 feeds four MFMAs), 32x32 blocks t = 2 jb + db,
 // wave w owns t = w and t = w + 8
@@ -178,6 +232,7 @@ __device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __res
         a[kg] = *reinterpret_cast<const f32x4*>(WtT + swzT(jx, kg * 2 + kh));
         bq[kg] = *reinterpret_cast<const f32x4*>(YtT + swzT(dx, kg * 2 + kh));
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kg = 0; kg < TI / 8; ++kg)
 #pragma unroll
@@ -187,8 +242,11 @@ __device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __res
 }
 
 // out[j0 + j, d] = X[j, d] * acc * scale for the blocks of col_product (X = the resident key-side LDS image)
-template <bool RAW = false>   // RAW: out = acc (backward products), else out = X . acc * scale (relprop rule)
-__device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float* __restrict__ Kt, float* __restrict__ out,
+// RAW: out = acc (backward products), else out = X . acc * scale (relprop rule) with X read from its [keys][64] LDS
+// image (XG == nullptr) or from global memory (XG + j * xsn + d)
+template <bool RAW, bool XGLOBAL>
+__device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float* __restrict__ Kt,
+                                             const float* __restrict__ XG, int64_t xsn, float* __restrict__ out,
                                              int64_t osn, int nj, int wave, int lr, int kh, int nblk, float scale) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -198,7 +256,16 @@ __device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int j = (t >> 1) * 32 + crow(e, kh);
-        if (j < nj) out[(int64_t)j * osn + d] = RAW ? acc[s][e] : (at64(Kt, j, d) * acc[s][e]) * scale;
+        if (j < nj) {
+          float val = acc[s][e];
+          if constexpr (!RAW) {
+            float x;
+            if constexpr (XGLOBAL) x = XG[(int64_t)j * xsn + d];
+            else x = at64(Kt, j, d);
+            val = (x * val) * scale;
+          }
+          out[(int64_t)j * osn + d] = val;
+        }
       }
     }
   }
@@ -269,27 +336,32 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
       // G = S v^T for key block `wave`; cam_attn = attn . G
       f32x16 gacc;
       zero16(gacc);
-#pragma unroll
-      for (int kg = 0; kg < 8; ++kg) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(St + swz64(lr, kg * 2 + kh));
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(Vt + swz64(wave * 32 + lr, kg * 2 + kh));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gacc = TE_MFMA32(a[j], bq[j], gacc);
-      }
       const int jl = wave * 32 + lr;
-      if (jl < nj) {
+      row_product32(gacc, St, lr, Vt, jl, kh);
+      if constexpr (MODE == RULE) {        // the block's sixteen attention values in one LDS round trip
+        float av[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int il = crow(e, kh);
-          if (i0 + il < N)
-            ca_bh[(int64_t)(i0 + il) * N + jl] = (MODE == RULE) ? (atT(WtT, jl, il) * gacc[e]) * scale : gacc[e];
+        for (int e = 0; e < 16; ++e) av[e] = atT(WtT, jl, crow(e, kh));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gacc[e] = (av[e] * gacc[e]) * scale;
+      }
+      float* dst = ca_bh + (int64_t)(i0 + 4 * kh) * N + jl;
+      const int nrow = N - i0 - 4 * kh;                       // rows of this half-wave's block that exist
+      if (jl < nj) {
+        if (nrow >= 28) {                                     // every row of the block exists: plain stores
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[(int64_t)((e & 3) + 8 * (e >> 2)) * N] = gacc[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if ((e & 3) + 8 * (e >> 2) < nrow) dst[(int64_t)((e & 3) + 8 * (e >> 2)) * N] = gacc[e];
         }
       }
     }
     col_product(accv, WtT, StT, wave, lr, kh, 2 * njb);
   }
   float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
-  col_epilogue<MODE == BWD>(accv, Vt, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
+  col_epilogue<MODE == BWD, false>(accv, Vt, v_bh, vs.sn, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -305,8 +377,8 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     const float* __restrict__ k, Strided ks, float* __restrict__ cam_q, Strided cqs, float* __restrict__ cam_k,
     Strided cks, float* __restrict__ qpart, int H, int N, int BH, int JG, int ngroups, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Kt = smem;                    // [NJMAX][64]
-  float* QtT = Kt + NJMAX * 64;        // [64][TI]   q tile transposed (column-side B operand)
+  float* KtT = smem;                   // [64][256]  k of this group TRANSPOSED (row-side B operand, K = key contiguous)
+  float* QtT = KtT + NJMAX * 64;       // [64][TI]   q tile transposed (column-side B operand)
   float* Wt = QtT + 64 * TI;           // [TI][256]  the S tile (row-side A operand, K = key contiguous)
   float* WtT = Wt + TI * WLD;          // [256][TI]  the S tile transposed (column-side A operand)
   float* Pt = WtT + NJMAX * TI;        // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
@@ -322,7 +394,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const WideMap wm = wide_map(nj32);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
 
-  stage_keys(Kt, k_bh, ks.sn, nj, nj32);
+  stage_keys_T(KtT, k_bh, ks.sn, nj, nj32);
   WideTile tr, tz;
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int it) __attribute__((always_inline)) {
@@ -386,25 +458,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
       // cam_q block (ib, db) = S[16 x keys] k[keys x 16]
       f32x4 cq = {0.f, 0.f, 0.f, 0.f};
       const int arow = ib * 16 + l15, dcol = db * 16 + l15;
-      // K = the group's keys, 32 per trip (nj32 is a multiple of 32): both A fragments and all eight B values of a
-      // trip are requested before its first MFMA, and two trips are unrolled so that the next trip's LDS reads issue
-      // under the current trip's MFMAs
-#pragma unroll 2
-      for (int kp = 0; kp < (nj32 >> 5); ++kp) {
-        f32x4 a[2];
-        float bv[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int kg = kp * 2 + u;
-          a[u] = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kg * 4 + kq));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[u][j] = at64(Kt, kg * 16 + kq * 4 + j, dcol);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) cq = TE_MFMA16(a[u][j], bv[u][j], cq);
-      }
+      row_product16(cq, Wt, arow, KtT, dcol, kq, nj32);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int il = ib * 16 + kq * 4 + r;
@@ -421,7 +475,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     col_product(acck, WtT, QtT, wave, lr, kh, 2 * njb);
   }
   float* o_bh = cam_k + (int64_t)b * cks.sb + (int64_t)h * cks.sh + (int64_t)j0 * cks.sn;
-  col_epilogue<MODE == BWD>(acck, Kt, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
+  col_epilogue<MODE == BWD, true>(acck, KtT, k_bh, ks.sn, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
 }
 
 // cam_q[i,d] = q[i,d] * (sum over groups of qpart[g][bh][i][d], in group order) * scale
@@ -456,9 +510,9 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ attn, float* __restrict__ out, int H, int N,
                                                       float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Kt = smem;                    // [NJF][64]
-  float* Vt = Kt + NJF * 64;           // [NJF][64]
-  float* Qt = Vt + NJF * 64;           // [TI][64]
+  float* Kt = smem;                    // [NJF][64]   k (row-side B operand of q k^T, K = d contiguous)
+  float* VtT = Kt + NJF * 64;          // [64][256]   v TRANSPOSED (row-side B operand of P v, K = key contiguous)
+  float* Qt = VtT + 64 * WLD;          // [TI][64]
   float* Wt = Qt + TI * 64;            // [TI][256]: scaled scores, then probabilities
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int C = H * 64;
@@ -474,7 +528,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
   const int ntiles = (N + TI - 1) / TI;
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
   stage_keys(Kt, k_bh, sn, nj, nj32);
-  stage_keys(Vt, v_bh, sn, nj, nj32);
+  stage_keys_T(VtT, v_bh, sn, nj, nj32);
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int it) __attribute__((always_inline)) {
     const int i0 = it * TI;
@@ -493,13 +547,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
       // scores of key block `wave`: z = q k^T
       f32x16 z;
       zero16(z);
-#pragma unroll
-      for (int kg = 0; kg < 8; ++kg) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Qt + swz64(lr, kg * 2 + kh));
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(Kt + swz64(wave * 32 + lr, kg * 2 + kh));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) z = TE_MFMA32(a[j], bq[j], z);
-      }
+      row_product32(z, Qt, lr, Kt, wave * 32 + lr, kh);
       const int jl = wave * 32 + lr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -564,22 +612,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
       // out block (ib, db) = P[16 x keys] v[keys x 16]
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
       const int arow = ib * 16 + l15, dcol = db * 16 + l15;
-#pragma unroll 2
-      for (int kp = 0; kp < (nj32 >> 5); ++kp) {
-        f32x4 a[2];
-        float bv[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int kg = kp * 2 + u;
-          a[u] = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kg * 4 + kq));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[u][j] = at64(Vt, kg * 16 + kq * 4 + j, dcol);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o = TE_MFMA16(a[u][j], bv[u][j], o);
-      }
+      row_product16(o, Wt, arow, VtT, dcol, kq, nj32);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int il = ib * 16 + kq * 4 + r;
@@ -592,7 +625,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
 constexpr size_t kLdsAv = (size_t)(NJMAX * 64 + 2 * TI * 64 + NJMAX * TI) * sizeof(float);                // 112 KB
 constexpr size_t kLdsQk = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD + NJMAX * TI) * sizeof(float);        // 136 KB
 constexpr size_t kLdsQkBwd = kLdsQk + (size_t)TI * 64 * sizeof(float);                                    // + rowdot scratch
-constexpr size_t kLdsFwd = (size_t)(2 * NJF * 64 + TI * 64 + TI * WLD) * sizeof(float);        // 152 KB
+constexpr size_t kLdsFwd = (size_t)(NJF * 64 + 64 * WLD + TI * 64 + TI * WLD) * sizeof(float);   // 160 KB: all of a CU's LDS
 
 inline void groups_for(int64_t N, int& ng, int& jg) {
   ng = (int)((N + NJMAX - 1) / NJMAX);
