@@ -130,6 +130,13 @@ __device__ __forceinline__ void load_wide(WideTile& t, const WideMap& m, const f
     t.v[r] = v;
   }
 }
+// slot r alone (the slots of the next tile are requested one at a time between the MFMA groups of the current one)
+__device__ __forceinline__ f32x4 load_wide_slot(const WideMap& m, int r, const float* __restrict__ src, int64_t ld,
+                                                int rows_valid, int cols_valid) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (m.row[r] >= 0 && m.row[r] < rows_valid) v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid);
+  return v;
+}
 __device__ __forceinline__ void store_wide(float* __restrict__ lds, const WideMap& m, const WideTile& t) {
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -164,20 +171,31 @@ __device__ __forceinline__ void stage_keys(float* __restrict__ Kt, const float* 
 
 // row-side product with a 32x32 output block:  acc += A[32 x 64] B[32 x 64]^T, both K-contiguous [rows][64] images.
 // All sixteen fragments are requested before the first MFMA (one LDS round trip per product instead of one per
-// four MFMAs -- hipcc otherwise waits lgkmcnt(0) in front of every group).
-__device__ __forceinline__ void row_product32(f32x16& acc, const float* __restrict__ At, int arow,
-                                              const float* __restrict__ Bt, int brow, int kh) {
+// four MFMAs -- hipcc otherwise waits lgkmcnt(0) in front of every group).  `between(kg)` runs after the kg-th group
+// of four MFMAs (kg = 0..7, also when the wave has no block: active == false): the caller issues ONE global memory
+// instruction there, so that the next tile's loads stream under the MFMAs instead of queueing up in a separate phase
+// -- a CU moves ~10 B per clock from HBM, a tile needs ~6500 clocks of that, about as long as its MFMAs.
+template <class F>
+__device__ __forceinline__ void row_product32(f32x16& acc, bool active, const float* __restrict__ At, int arow,
+                                              const float* __restrict__ Bt, int brow, int kh, F&& between) {
   f32x4 a[8], bq[8];
+  if (active) {
 #pragma unroll
-  for (int kg = 0; kg < 8; ++kg) {
-    a[kg] = *reinterpret_cast<const f32x4*>(At + swz64(arow, kg * 2 + kh));
-    bq[kg] = *reinterpret_cast<const f32x4*>(Bt + swz64(brow, kg * 2 + kh));
+    for (int kg = 0; kg < 8; ++kg) {
+      a[kg] = *reinterpret_cast<const f32x4*>(At + swz64(arow, kg * 2 + kh));
+      bq[kg] = *reinterpret_cast<const f32x4*>(Bt + swz64(brow, kg * 2 + kh));
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int kg = 0; kg < 8; ++kg)
+  for (int kg = 0; kg < 8; ++kg) {
+    if (active) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = TE_MFMA32(a[kg][j], bq[kg][j], acc);
+      for (int j = 0; j < 4; ++j) acc = TE_MFMA32(a[kg][j], bq[kg][j], acc);
+    }
+    between(kg);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // row-side product with a 16x16 output block over K = nj32 keys:  acc += W[16 x keys] X[keys x 16], W = the
@@ -218,30 +236,37 @@ __device__ __forceinline__ void stage_keys_T(float* __restrict__ KtT, const floa
 
 // column-side product of one row tile:  acc[(jb, db)] += W^T[keys x 32] Y[32 x 64] from the TRANSPOSED images
 // WtT [keys][32] and YtT [64][32] (both K-contiguous: one ds_read_b128 feeds four MFMAs), 32x32 blocks t = 2 jb + db,
-// wave w owns t = w and t = w + 8
+// wave w owns t = w and t = w + 8.  `between(g)`, g = 0..7, runs after every group of four MFMAs (whether or not the
+// wave owns a block there): one global memory instruction of the caller per group.
+template <class F>
 __device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __restrict__ WtT, const float* __restrict__ YtT,
-                                            int wave, int lr, int kh, int nblk) {
+                                            int wave, int lr, int kh, int nblk, F&& between) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int t = wave + s * kWaves;
-    if (t < nblk) {
-      const int jx = (t >> 1) * 32 + lr, dx = (t & 1) * 32 + lr;
-      f32x4 a[TI / 8], bq[TI / 8];
+    const bool active = t < nblk;
+    const int jx = (t >> 1) * 32 + lr, dx = (t & 1) * 32 + lr;
+    f32x4 a[TI / 8], bq[TI / 8];
+    if (active) {
 #pragma unroll
       for (int kg = 0; kg < TI / 8; ++kg) {
         a[kg] = *reinterpret_cast<const f32x4*>(WtT + swzT(jx, kg * 2 + kh));
         bq[kg] = *reinterpret_cast<const f32x4*>(YtT + swzT(dx, kg * 2 + kh));
       }
-      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int kg = 0; kg < TI / 8; ++kg)
+    for (int kg = 0; kg < TI / 8; ++kg) {
+      if (active) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[s] = TE_MFMA32(a[kg][j], bq[kg][j], acc[s]);
+      }
+      between(s * (TI / 8) + kg);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-// out[j0 + j, d] = X[j, d] * acc * scale for the blocks of col_product (X = the resident key-side LDS image)
 // RAW: out = acc (backward products), else out = X . acc * scale (relprop rule) with X read from its [keys][64] LDS
 // image (XG == nullptr) or from global memory (XG + j * xsn + d)
 template <bool RAW, bool XGLOBAL>
@@ -277,12 +302,24 @@ __device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float
 // ------------------------------------------------------------------------------------------------
 enum { RULE = 0, BWD = 1 };
 
+// Phase timing of workgroup 0 (tuning aid, TE_ATTN_PROF=1 via te_attn_rules_profile()): prof[wave * 8 + phase]
+// accumulates shader-clock cycles between the marks of one tile; nullptr in every normal launch.
+#define TE_MARK(slot)                                                          \
+  do {                                                                         \
+    if (prof != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {       \
+      const long long now__ = clock64();                                       \
+      prof[(threadIdx.x >> 6) * 8 + (slot)] += now__ - tprev;                  \
+      tprev = now__;                                                           \
+    }                                                                          \
+  } while (0)
+
 template <int MODE>
 __global__ __launch_bounds__(kT) void av_rule_kernel(
     const float* __restrict__ R, Strided rs, const float* __restrict__ Z, Strided zs, const float* __restrict__ attn,
     const float* __restrict__ v, Strided vs, float* __restrict__ cam_attn, float* __restrict__ cam_v, Strided cs, int H,
-    int N, int BH, int JG, float scale) {
+    int N, int BH, int JG, float scale, long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  long long tprev = prof ? clock64() : 0;
   float* Vt = smem;                    // [NJMAX][64]
   float* St = Vt + NJMAX * 64;         // [TI][64]   S (row-side A operand, K = d contiguous)
   float* StT = St + TI * 64;           // [64][TI]   S transposed (column-side B operand, K = query row contiguous)
@@ -290,7 +327,7 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
   const float* r_bh = R + (int64_t)b * rs.sb + (int64_t)h * rs.sh;
   const float* z_bh = (MODE == RULE) ? Z + (int64_t)b * zs.sb + (int64_t)h * zs.sh : nullptr;
   const float* a_bh = attn + (int64_t)bh * N * N + j0;
@@ -303,23 +340,30 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   stage_keys(Vt, v_bh, vs.sn, nj, nj32);
   WideTile ta;
   f32x4 rr = {0.f, 0.f, 0.f, 0.f}, zz = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](int it) __attribute__((always_inline)) {
+  // part p = 0..5 of tile `it`: the four float4 slots of the attn tile, then the R and Z float4 of the S tile
+  auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
-    load_wide(ta, wm, a_bh + (int64_t)i0 * N, N, rows_valid, nj);
-    rr = zz = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (srow < rows_valid) {
-      rr = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(i0 + srow) * rs.sn + (sc << 2));
+    if (p < 4) {
+      ta.v[p] = load_wide_slot(wm, p, a_bh + (int64_t)i0 * N, N, rows_valid, nj);
+    } else if (p == 4) {
+      rr = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (srow < rows_valid) rr = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(i0 + srow) * rs.sn + (sc << 2));
+    } else if (p == 5) {
+      zz = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (MODE == RULE)
-        zz = *reinterpret_cast<const f32x4_u*>(z_bh + (int64_t)(i0 + srow) * zs.sn + (sc << 2));
+        if (srow < rows_valid) zz = *reinterpret_cast<const f32x4_u*>(z_bh + (int64_t)(i0 + srow) * zs.sn + (sc << 2));
     }
   };
-  fetch(0);
+#pragma unroll
+  for (int p = 0; p < 6; ++p) fetch_part(0, p);
   f32x16 accv[2];
   zero16(accv[0]);
   zero16(accv[1]);
   for (int it = 0; it < ntiles; ++it) {
     const int i0 = it * TI;
+    TE_MARK(0);
     __syncthreads();                       // the previous tile's readers are done (first trip: nothing to wait for)
+    TE_MARK(1);
     {
       f32x4 s = rr;                                                  // BWD: the tile of d_out itself
       if constexpr (MODE == RULE) {
@@ -330,35 +374,39 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
       store_small_T(StT, srow, sc, s);
       store_wide_T(WtT, wm, ta);
     }
+    TE_MARK(2);
     __syncthreads();
-    if (it + 1 < ntiles) fetch(it + 1);
-    if (wave < njb) {
-      // G = S v^T for key block `wave`; cam_attn = attn . G
-      f32x16 gacc;
-      zero16(gacc);
-      const int jl = wave * 32 + lr;
-      row_product32(gacc, St, lr, Vt, jl, kh);
-      if constexpr (MODE == RULE) {        // the block's sixteen attention values in one LDS round trip
+    TE_MARK(3);
+    // G = S v^T for key block `wave`; the six loads of the next tile go out one per MFMA group
+    f32x16 gacc;
+    zero16(gacc);
+    const int jl = wave * 32 + lr;
+    const bool more = it + 1 < ntiles;
+    row_product32(gacc, wave < njb, St, lr, Vt, jl, kh, [&](int kg) __attribute__((always_inline)) {
+      if (more && kg < 6) fetch_part(it + 1, kg);
+    });
+    TE_MARK(4);
+    if constexpr (MODE == RULE) {          // cam_attn = attn . G: the block's sixteen attention values in one LDS round trip
+      if (wave < njb) {
         float av[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) av[e] = atT(WtT, jl, crow(e, kh));
 #pragma unroll
         for (int e = 0; e < 16; ++e) gacc[e] = (av[e] * gacc[e]) * scale;
       }
-      float* dst = ca_bh + (int64_t)(i0 + 4 * kh) * N + jl;
-      const int nrow = N - i0 - 4 * kh;                       // rows of this half-wave's block that exist
-      if (jl < nj) {
-        if (nrow >= 28) {                                     // every row of the block exists: plain stores
-#pragma unroll
-          for (int e = 0; e < 16; ++e) dst[(int64_t)((e & 3) + 8 * (e >> 2)) * N] = gacc[e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if ((e & 3) + 8 * (e >> 2) < nrow) dst[(int64_t)((e & 3) + 8 * (e >> 2)) * N] = gacc[e];
-        }
-      }
     }
-    col_product(accv, WtT, StT, wave, lr, kh, 2 * njb);
+    TE_MARK(5);
+    // column side; the sixteen row stores of the block go out two per MFMA group
+    float* dst = ca_bh + (int64_t)(i0 + 4 * kh) * N + jl;
+    const int nrow = (wave < njb && jl < nj) ? N - i0 - 4 * kh : 0;      // rows of this half-wave's block to store
+    col_product(accv, WtT, StT, wave, lr, kh, 2 * njb, [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = 2 * g + u, off = (e & 3) + 8 * (e >> 2);
+        if (off < nrow) dst[(int64_t)off * N] = gacc[e];
+      }
+    });
+    TE_MARK(6);
   }
   float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
   col_epilogue<MODE == BWD, false>(accv, Vt, v_bh, vs.sn, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
@@ -375,8 +423,10 @@ template <int MODE>
 __global__ __launch_bounds__(kT) void qk_rule_kernel(
     const float* __restrict__ Rnn, const float* __restrict__ Z, const float* __restrict__ q, Strided qs,
     const float* __restrict__ k, Strided ks, float* __restrict__ cam_q, Strided cqs, float* __restrict__ cam_k,
-    Strided cks, float* __restrict__ qpart, int H, int N, int BH, int JG, int ngroups, float scale) {
+    Strided cks, float* __restrict__ qpart, int H, int N, int BH, int JG, int ngroups, float scale,
+    long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  long long tprev = prof ? clock64() : 0;
   float* KtT = smem;                   // [64][256]  k of this group TRANSPOSED (row-side B operand, K = key contiguous)
   float* QtT = KtT + NJMAX * 64;       // [64][TI]   q tile transposed (column-side B operand)
   float* Wt = QtT + 64 * TI;           // [TI][256]  the S tile (row-side A operand, K = key contiguous)
@@ -385,7 +435,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
   const float* r_bh = Rnn + (int64_t)bh * N * N + j0;
   const float* z_bh = Z + (int64_t)bh * N * N + j0;
   const float* q_bh = q + (int64_t)b * qs.sb + (int64_t)h * qs.sh;
@@ -397,14 +447,20 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   stage_keys_T(KtT, k_bh, ks.sn, nj, nj32);
   WideTile tr, tz;
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](int it) __attribute__((always_inline)) {
+  // part p = 0..8 of tile `it`: the four float4 slots of the R tile, of the Z tile, then the q float4
+  auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
-    load_wide(tr, wm, r_bh + (int64_t)i0 * N, N, rows_valid, nj);
-    load_wide(tz, wm, z_bh + (int64_t)i0 * N, N, rows_valid, nj);
-    qq = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (srow < rows_valid) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * qs.sn + (sc << 2));
+    if (p < 4) {
+      tr.v[p] = load_wide_slot(wm, p, r_bh + (int64_t)i0 * N, N, rows_valid, nj);
+    } else if (p < 8) {
+      tz.v[p - 4] = load_wide_slot(wm, p - 4, z_bh + (int64_t)i0 * N, N, rows_valid, nj);
+    } else {
+      qq = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (srow < rows_valid) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * qs.sn + (sc << 2));
+    }
   };
-  fetch(0);
+#pragma unroll
+  for (int p = 0; p < 9; ++p) fetch_part(0, p);
   f32x16 acck[2];
   zero16(acck[0]);
   zero16(acck[1]);
@@ -412,7 +468,9 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const int ib = wave >> 2, db = wave & 3, l15 = lane & 15, kq = lane >> 4;
   for (int it = 0; it < ntiles; ++it) {
     const int i0 = it * TI;
+    TE_MARK(0);
     __syncthreads();
+    TE_MARK(1);
     if constexpr (MODE == RULE) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -452,13 +510,24 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     store_wide(Wt, wm, tr);
     store_wide_T(WtT, wm, tr);
     store_small_T(QtT, srow, sc, qq);
+    TE_MARK(2);
     __syncthreads();
-    if (it + 1 < ntiles) fetch(it + 1);
+    TE_MARK(3);
+    // column side first: the nine loads of the next tile go out one per MFMA group (two with the first)
+    const bool more = it + 1 < ntiles;
+    col_product(acck, WtT, QtT, wave, lr, kh, 2 * njb, [&](int g) __attribute__((always_inline)) {
+      if (more) {
+        fetch_part(it + 1, g);
+        if (g == 7) fetch_part(it + 1, 8);
+      }
+    });
+    TE_MARK(4);
     {
       // cam_q block (ib, db) = S[16 x keys] k[keys x 16]
       f32x4 cq = {0.f, 0.f, 0.f, 0.f};
       const int arow = ib * 16 + l15, dcol = db * 16 + l15;
       row_product16(cq, Wt, arow, KtT, dcol, kq, nj32);
+      TE_MARK(5);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int il = ib * 16 + kq * 4 + r;
@@ -472,7 +541,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
         }
       }
     }
-    col_product(acck, WtT, QtT, wave, lr, kh, 2 * njb);
+    TE_MARK(6);
   }
   float* o_bh = cam_k + (int64_t)b * cks.sb + (int64_t)h * cks.sh + (int64_t)j0 * cks.sn;
   col_epilogue<MODE == BWD, true>(acck, KtT, k_bh, ks.sn, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
@@ -547,7 +616,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
       // scores of key block `wave`: z = q k^T
       f32x16 z;
       zero16(z);
-      row_product32(z, Qt, lr, Kt, wave * 32 + lr, kh);
+      row_product32(z, true, Qt, lr, Kt, wave * 32 + lr, kh, [](int) {});
       const int jl = wave * 32 + lr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -639,6 +708,12 @@ inline void allow_lds(K kern, size_t bytes) {
 
 }  // namespace
 
+// tuning aid: device buffer of 2 x 64 counters (AV kernel, QK kernel) the next launches accumulate into; NULL = off
+static long long* g_prof = nullptr;
+}  // namespace te_attn_rules
+extern "C" void te_attn_rules_profile(long long* device_buffer) { te_attn_rules::g_prof = device_buffer; }
+namespace te_attn_rules {
+
 bool enabled() {
   // TE_ATTN_IMPL=tiles selects the 64 x 64-tile kernels of te_attn_mfma.hip (kept as the on-device cross-check)
   static const bool on = [] {
@@ -664,7 +739,7 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
   allow_lds(av_rule_kernel<RULE>, kLdsAv);
   av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLdsAv, stream>>>(
       R, Strided{r_sb, r_sh, r_sn}, Z, Strided{z_sb, z_sh, z_sn}, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v,
-      Strided{cv_sb, cv_sh, cv_sn}, (int)H, (int)N, BH, jg, scale);
+      Strided{cv_sb, cv_sh, cv_sn}, (int)H, (int)N, BH, jg, scale, g_prof);
   return TE_OK;
 }
 
@@ -679,7 +754,7 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
   qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLdsQk, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
                                                                               cks, qpart, (int)H, (int)N, BH, jg, ng,
-                                                                              scale);
+                                                                              scale, g_prof ? g_prof + 64 : nullptr);
   if (ng > 1) {
     const int64_t n4 = (int64_t)BH * N * 16;
     qk_finish_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(qpart, q, qs, cam_q, cqs, (int)H,
@@ -728,13 +803,13 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
   allow_lds(av_rule_kernel<BWD>, kLdsAv);
   av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsAv, stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
                                                                       qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
-                                                                      (int)H, (int)N, BH, jg, 1.0f);
+                                                                      (int)H, (int)N, BH, jg, 1.0f, nullptr);
   if (need_qk) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q
     allow_lds(qk_rule_kernel<BWD>, kLdsQkBwd);
     qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsQkBwd, stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
                                                                            d_qkv, fused, d_qkv + C, fused, nullptr,
-                                                                           (int)H, (int)N, BH, jg, 1, scale);
+                                                                           (int)H, (int)N, BH, jg, 1, scale, nullptr);
   }
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
