@@ -89,10 +89,16 @@ __device__ __forceinline__ void zero16(f32x16& a) {
 }
 
 // guarded 4-wide access at a dword-aligned address: elements [c, c+4) of a row with `cols_valid` valid columns
-__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int c, int cols_valid) {
+// `spill_ok`: the 16 bytes at p + c lie inside the tensor even where they run past the row's valid columns (every row
+// but the very last one of the whole [B*H,N,N] tensor): ONE 16-B load, invalid elements zeroed afterwards -- the
+// element-wise tail costs four extra (mostly masked) memory instructions per slot for every wave that touches a row
+// end, i.e. every wave at N = 197, and a CU's memory pipe is issue-bound long before it is byte-bound.
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int c, int cols_valid, bool spill_ok = false) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (c + 3 < cols_valid) {
+  if (c + 3 < cols_valid || (spill_ok && c < cols_valid)) {
     v = *reinterpret_cast<const f32x4_u*>(p + c);
+#pragma unroll
+    for (int e = 1; e < 4; ++e) v[e] = (c + e < cols_valid) ? v[e] : 0.0f;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -131,11 +137,43 @@ __device__ __forceinline__ void load_wide(WideTile& t, const WideMap& m, const f
   }
 }
 // slot r alone (the slots of the next tile are requested one at a time between the MFMA groups of the current one)
+// rows_safe: rows [0, rows_safe) of this tile are not the last row of the whole tensor (reading past their end is fine)
 __device__ __forceinline__ f32x4 load_wide_slot(const WideMap& m, int r, const float* __restrict__ src, int64_t ld,
-                                                int rows_valid, int cols_valid) {
+                                                int rows_valid, int cols_valid, int rows_safe) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (m.row[r] >= 0 && m.row[r] < rows_valid) v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid);
+  if (m.row[r] >= 0 && m.row[r] < rows_valid)
+    v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid, m.row[r] < rows_safe);
   return v;
+}
+// coalesced 16-B stores of a [TI][nj] tile held in the [TI][256] LDS image (the same slot mapping as the loads).
+// A float4 that runs past the end of row i continues into the first elements of row i + 1 in memory: when that row is
+// part of this tile too (`row_end`: the columns end where the tensor's rows end), the 16-B store carries those
+// elements along (the owner of row i + 1's first float4 writes the same values again) instead of falling back to
+// element-wise stores -- which would cost four masked store instructions per slot for every wave at N = 197.
+__device__ __forceinline__ void store_wide_global(const float* __restrict__ lds, const WideMap& m, float* __restrict__ dst,
+                                                  int64_t ld, int rows_valid, int cols_valid, bool row_end) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m.row[r] >= 0 && m.row[r] < rows_valid) {
+      const int c = m.c4[r] << 2;
+      if (c < cols_valid) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(lds + swzw(m.row[r], m.c4[r]));
+        float* p = dst + (int64_t)m.row[r] * ld + c;
+        if (c + 3 < cols_valid) {
+          *reinterpret_cast<f32x4_u*>(p) = v;
+        } else if (row_end && m.row[r] + 1 < rows_valid) {
+          const f32x4 nx = *reinterpret_cast<const f32x4*>(lds + swzw(m.row[r] + 1, 0));
+          const int nv = cols_valid - c;                       // 1..3 valid elements of this row
+#pragma unroll
+          for (int e = 1; e < 4; ++e) v[e] = (e < nv) ? v[e] : nx[e - nv];
+          *reinterpret_cast<f32x4_u*>(p) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < cols_valid) p[e] = v[e];
+        }
+      }
+    }
 }
 __device__ __forceinline__ void store_wide(float* __restrict__ lds, const WideMap& m, const WideTile& t) {
 #pragma unroll
@@ -324,6 +362,7 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   float* St = Vt + NJMAX * 64;         // [TI][64]   S (row-side A operand, K = d contiguous)
   float* StT = St + TI * 64;           // [64][TI]   S transposed (column-side B operand, K = query row contiguous)
   float* WtT = StT + 64 * TI;          // [256][TI]  the attn tile, transposed (column-side A operand)
+  float* Ct = WtT + NJMAX * TI;        // [TI][256]  cam_attn of the tile, staged for coalesced 16-B row stores
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -336,6 +375,8 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   const int ntiles = (N + TI - 1) / TI;
   const WideMap wm = wide_map(nj32);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;      // this thread's float4 of the [32][64] S tile
+  // rows of tile i0 after which the tensor continues (all but the last row of the last (b,h)): load4's spill_ok
+  auto rows_safe = [&](int i0) __attribute__((always_inline)) { return (bh == BH - 1) ? N - 1 - i0 : TI; };
 
   stage_keys(Vt, v_bh, vs.sn, nj, nj32);
   WideTile ta;
@@ -344,7 +385,7 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
     if (p < 4) {
-      ta.v[p] = load_wide_slot(wm, p, a_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      ta.v[p] = load_wide_slot(wm, p, a_bh + (int64_t)i0 * N, N, rows_valid, nj, rows_safe(i0));
     } else if (p == 4) {
       rr = f32x4{0.f, 0.f, 0.f, 0.f};
       if (srow < rows_valid) rr = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(i0 + srow) * rs.sn + (sc << 2));
@@ -373,6 +414,8 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
       *reinterpret_cast<f32x4*>(St + swz64(srow, sc)) = s;
       store_small_T(StT, srow, sc, s);
       store_wide_T(WtT, wm, ta);
+      // cam_attn of the PREVIOUS tile: whole rows as 16-B stores from its LDS image
+      if (it > 0) store_wide_global(Ct, wm, ca_bh + (int64_t)(i0 - TI) * N, N, TI, nj, j0 + nj == N);
     }
     TE_MARK(2);
     __syncthreads();
@@ -395,18 +438,18 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
         for (int e = 0; e < 16; ++e) gacc[e] = (av[e] * gacc[e]) * scale;
       }
     }
-    TE_MARK(5);
-    // column side; the sixteen row stores of the block go out two per MFMA group
-    float* dst = ca_bh + (int64_t)(i0 + 4 * kh) * N + jl;
-    const int nrow = (wave < njb && jl < nj) ? N - i0 - 4 * kh : 0;      // rows of this half-wave's block to store
-    col_product(accv, WtT, StT, wave, lr, kh, 2 * njb, [&](int g) __attribute__((always_inline)) {
+    if (wave < njb) {                      // stage the block for the coalesced row stores of the next trip
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = 2 * g + u, off = (e & 3) + 8 * (e >> 2);
-        if (off < nrow) dst[(int64_t)off * N] = gacc[e];
-      }
-    });
+      for (int e = 0; e < 16; ++e) Ct[swzw(crow(e, kh), jl >> 2) + (jl & 3)] = gacc[e];
+    }
+    TE_MARK(5);
+    col_product(accv, WtT, StT, wave, lr, kh, 2 * njb, [](int) {});
     TE_MARK(6);
+  }
+  __syncthreads();
+  {
+    const int i0 = (ntiles - 1) * TI;
+    store_wide_global(Ct, wm, ca_bh + (int64_t)i0 * N, N, min(TI, N - i0), nj, j0 + nj == N);
   }
   float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
   col_epilogue<MODE == BWD, false>(accv, Vt, v_bh, vs.sn, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
@@ -443,6 +486,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const int ntiles = (N + TI - 1) / TI;
   const WideMap wm = wide_map(nj32);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
+  auto rows_safe = [&](int i0) __attribute__((always_inline)) { return (bh == BH - 1) ? N - 1 - i0 : TI; };
 
   stage_keys_T(KtT, k_bh, ks.sn, nj, nj32);
   WideTile tr, tz;
@@ -451,9 +495,9 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
     if (p < 4) {
-      tr.v[p] = load_wide_slot(wm, p, r_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      tr.v[p] = load_wide_slot(wm, p, r_bh + (int64_t)i0 * N, N, rows_valid, nj, rows_safe(i0));
     } else if (p < 8) {
-      tz.v[p - 4] = load_wide_slot(wm, p - 4, z_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      tz.v[p - 4] = load_wide_slot(wm, p - 4, z_bh + (int64_t)i0 * N, N, rows_valid, nj, rows_safe(i0));
     } else {
       qq = f32x4{0.f, 0.f, 0.f, 0.f};
       if (srow < rows_valid) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * qs.sn + (sc << 2));
@@ -619,11 +663,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
       row_product32(z, true, Qt, lr, Kt, wave * 32 + lr, kh, [](int) {});
       const int jl = wave * 32 + lr;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int il = crow(e, kh);
-        if (jl < nj && i0 + il < N) z_bh[(int64_t)(i0 + il) * N + jl] = z[e];
-        Wt[swzw(il, jl >> 2) + (jl & 3)] = z[e] * scale;       // 'dots = einsum(...) * self.scale' (ViT_LRP.py:139)
-      }
+      for (int e = 0; e < 16; ++e) Wt[swzw(crow(e, kh), jl >> 2) + (jl & 3)] = z[e];      // unscaled scores
     }
     __syncthreads();
     {
@@ -636,9 +676,20 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
         x[m] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         if (c * 4 < nj32) {
           x[m] = *reinterpret_cast<const f32x4*>(Wt + swzw(srow, c));
+          // z_qk leaves as whole-row 16-B stores from here (the accumulator layout would need a dword store per element)
+          if (i0 + srow < N) {
+            float* zdst = z_bh + (int64_t)(i0 + srow) * N + c * 4;
+            if (c * 4 + 3 < nj) {
+              *reinterpret_cast<f32x4_u*>(zdst) = x[m];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (c * 4 + e < nj) zdst[e] = x[m][e];
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (c * 4 + e >= nj) x[m][e] = -INFINITY;
+            x[m][e] = (c * 4 + e < nj) ? x[m][e] * scale : -INFINITY;      // 'dots = einsum(...) * self.scale' (ViT_LRP.py:139)
             mx = fmaxf(mx, x[m][e]);
           }
         }
@@ -691,7 +742,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
   }
 }
 
-constexpr size_t kLdsAv = (size_t)(NJMAX * 64 + 2 * TI * 64 + NJMAX * TI) * sizeof(float);                // 112 KB
+constexpr size_t kLdsAv = (size_t)(NJMAX * 64 + 2 * TI * 64 + NJMAX * TI + TI * WLD) * sizeof(float);     // 144 KB
 constexpr size_t kLdsQk = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD + NJMAX * TI) * sizeof(float);        // 136 KB
 constexpr size_t kLdsQkBwd = kLdsQk + (size_t)TI * 64 * sizeof(float);                                    // + rowdot scratch
 constexpr size_t kLdsFwd = (size_t)(NJF * 64 + 64 * WLD + TI * 64 + TI * WLD) * sizeof(float);   // 160 KB: all of a CU's LDS
