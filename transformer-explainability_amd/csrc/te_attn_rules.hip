@@ -64,15 +64,16 @@ typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 #define TE_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ (row & 15)) << 2); }
-__device__ __forceinline__ int swzw(int row, int chunk) {
-  return row * WLD + (((chunk & ~15) | ((chunk ^ row) & 15)) << 2);
+// (ld = floats per row, a multiple of 64: the keys of a group, <= 256)
+__device__ __forceinline__ int swzw(int row, int chunk, int ld = WLD) {
+  return row * ld + (((chunk & ~15) | ((chunk ^ row) & 15)) << 2);
 }
 // element (row, x) of a swizzled tile
 __device__ __forceinline__ float at64(const float* __restrict__ T, int row, int x) {
   return T[swz64(row, x >> 2) + (x & 3)];
 }
-__device__ __forceinline__ float atw(const float* __restrict__ T, int row, int x) {
-  return T[swzw(row, x >> 2) + (x & 3)];
+__device__ __forceinline__ float atw(const float* __restrict__ T, int row, int x, int ld = WLD) {
+  return T[swzw(row, x >> 2, ld) + (x & 3)];
 }
 // TRANSPOSED images for the column-side products ([x][32 query rows], 128-B rows, K = query row contiguous): chunk
 // XOR-ed by ((x >> 1) ^ (x >> 4)) & 7 -- conflict-free ds_read_b128 over the 16 rows of a lane group (te_linear.hip's
@@ -89,16 +90,10 @@ __device__ __forceinline__ void zero16(f32x16& a) {
 }
 
 // guarded 4-wide access at a dword-aligned address: elements [c, c+4) of a row with `cols_valid` valid columns
-// `spill_ok`: the 16 bytes at p + c lie inside the tensor even where they run past the row's valid columns (every row
-// but the very last one of the whole [B*H,N,N] tensor): ONE 16-B load, invalid elements zeroed afterwards -- the
-// element-wise tail costs four extra (mostly masked) memory instructions per slot for every wave that touches a row
-// end, i.e. every wave at N = 197, and a CU's memory pipe is issue-bound long before it is byte-bound.
-__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int c, int cols_valid, bool spill_ok = false) {
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int c, int cols_valid) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (c + 3 < cols_valid || (spill_ok && c < cols_valid)) {
+  if (c + 3 < cols_valid) {
     v = *reinterpret_cast<const f32x4_u*>(p + c);
-#pragma unroll
-    for (int e = 1; e < 4; ++e) v[e] = (c + e < cols_valid) ? v[e] : 0.0f;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -136,49 +131,17 @@ __device__ __forceinline__ void load_wide(WideTile& t, const WideMap& m, const f
     t.v[r] = v;
   }
 }
-// slot r alone (the slots of the next tile are requested one at a time between the MFMA groups of the current one)
-// rows_safe: rows [0, rows_safe) of this tile are not the last row of the whole tensor (reading past their end is fine)
+// slot r alone (the QK kernel requests the next tile's slots one at a time between its MFMA groups)
 __device__ __forceinline__ f32x4 load_wide_slot(const WideMap& m, int r, const float* __restrict__ src, int64_t ld,
-                                                int rows_valid, int cols_valid, int rows_safe) {
+                                                int rows_valid, int cols_valid) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (m.row[r] >= 0 && m.row[r] < rows_valid)
-    v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid, m.row[r] < rows_safe);
+  if (m.row[r] >= 0 && m.row[r] < rows_valid) v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid);
   return v;
 }
-// coalesced 16-B stores of a [TI][nj] tile held in the [TI][256] LDS image (the same slot mapping as the loads).
-// A float4 that runs past the end of row i continues into the first elements of row i + 1 in memory: when that row is
-// part of this tile too (`row_end`: the columns end where the tensor's rows end), the 16-B store carries those
-// elements along (the owner of row i + 1's first float4 writes the same values again) instead of falling back to
-// element-wise stores -- which would cost four masked store instructions per slot for every wave at N = 197.
-__device__ __forceinline__ void store_wide_global(const float* __restrict__ lds, const WideMap& m, float* __restrict__ dst,
-                                                  int64_t ld, int rows_valid, int cols_valid, bool row_end) {
+__device__ __forceinline__ void store_wide(float* __restrict__ lds, const WideMap& m, const WideTile& t, int ld) {
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    if (m.row[r] >= 0 && m.row[r] < rows_valid) {
-      const int c = m.c4[r] << 2;
-      if (c < cols_valid) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(lds + swzw(m.row[r], m.c4[r]));
-        float* p = dst + (int64_t)m.row[r] * ld + c;
-        if (c + 3 < cols_valid) {
-          *reinterpret_cast<f32x4_u*>(p) = v;
-        } else if (row_end && m.row[r] + 1 < rows_valid) {
-          const f32x4 nx = *reinterpret_cast<const f32x4*>(lds + swzw(m.row[r] + 1, 0));
-          const int nv = cols_valid - c;                       // 1..3 valid elements of this row
-#pragma unroll
-          for (int e = 1; e < 4; ++e) v[e] = (e < nv) ? v[e] : nx[e - nv];
-          *reinterpret_cast<f32x4_u*>(p) = v;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c + e < cols_valid) p[e] = v[e];
-        }
-      }
-    }
-}
-__device__ __forceinline__ void store_wide(float* __restrict__ lds, const WideMap& m, const WideTile& t) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (m.row[r] >= 0) *reinterpret_cast<f32x4*>(lds + swzw(m.row[r], m.c4[r])) = t.v[r];
+    if (m.row[r] >= 0) *reinterpret_cast<f32x4*>(lds + swzw(m.row[r], m.c4[r], ld)) = t.v[r];
 }
 
 // the same tile transposed: element (row i, column x) -> T[x][i]
@@ -241,14 +204,14 @@ __device__ __forceinline__ void row_product32(f32x16& acc, bool active, const fl
 // read with ds_read_b128; software-pipelined two 16-key groups at a time (the next pair's fragments are requested
 // before the current pair's eight MFMAs).  nj32 is a multiple of 32.
 __device__ __forceinline__ void row_product16(f32x4& acc, const float* __restrict__ Wt, int arow,
-                                              const float* __restrict__ XtT, int dcol, int kq, int nj32) {
+                                              const float* __restrict__ XtT, int dcol, int kq, int nj32, int ld) {
   const int np = nj32 >> 5;
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kq)), a1 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, 4 + kq));
-  f32x4 b0 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, kq)), b1 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, 4 + kq));
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, kq, ld)), a1 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, 4 + kq, ld));
+  f32x4 b0 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, kq, ld)), b1 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, 4 + kq, ld));
   for (int kp = 0; kp < np; ++kp) {
     const int c = (kp + 1 < np) ? (kp + 1) * 8 + kq : kq;      // (last trip: a harmless re-read)
-    const f32x4 na0 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, c)), na1 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, c + 4));
-    const f32x4 nb0 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, c)), nb1 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, c + 4));
+    const f32x4 na0 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, c, ld)), na1 = *reinterpret_cast<const f32x4*>(Wt + swzw(arow, c + 4, ld));
+    const f32x4 nb0 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, c, ld)), nb1 = *reinterpret_cast<const f32x4*>(XtT + swzw(dcol, c + 4, ld));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = TE_MFMA16(a0[j], b0[j], acc);
@@ -262,13 +225,13 @@ __device__ __forceinline__ void row_product16(f32x4& acc, const float* __restric
 // key-side operand transposed: rows [j0, j0 + nj) of src [.,64] -> LDS [64][256] (element (j, d) at (d, j)), keys
 // >= nj zero
 __device__ __forceinline__ void stage_keys_T(float* __restrict__ KtT, const float* __restrict__ src, int64_t sn, int nj,
-                                             int nj32) {
+                                             int nj32, int ld) {
   for (int idx = threadIdx.x; idx < nj32 * 16; idx += kT) {
     const int row = idx >> 4, c = idx & 15;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row < nj) v = *reinterpret_cast<const f32x4_u*>(src + (int64_t)row * sn + (c << 2));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) KtT[swzw((c << 2) + e, row >> 2) + (row & 3)] = v[e];
+    for (int e = 0; e < 4; ++e) KtT[swzw((c << 2) + e, row >> 2, ld) + (row & 3)] = v[e];
   }
 }
 
@@ -358,11 +321,10 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
     int N, int BH, int JG, float scale, long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   long long tprev = prof ? clock64() : 0;
-  float* Vt = smem;                    // [NJMAX][64]
-  float* St = Vt + NJMAX * 64;         // [TI][64]   S (row-side A operand, K = d contiguous)
+  float* Vt = smem;                    // [JG][64]   v of this key group (JG = keys per group: 128 / 192 / 256)
+  float* St = Vt + JG * 64;            // [TI][64]   S (row-side A operand, K = d contiguous)
   float* StT = St + TI * 64;           // [64][TI]   S transposed (column-side B operand, K = query row contiguous)
-  float* WtT = StT + 64 * TI;          // [256][TI]  the attn tile, transposed (column-side A operand)
-  float* Ct = WtT + NJMAX * TI;        // [TI][256]  cam_attn of the tile, staged for coalesced 16-B row stores
+  float* WtT = StT + 64 * TI;          // [JG][TI]   the attn tile, transposed (column-side A operand)
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -375,8 +337,6 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   const int ntiles = (N + TI - 1) / TI;
   const WideMap wm = wide_map(nj32);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;      // this thread's float4 of the [32][64] S tile
-  // rows of tile i0 after which the tensor continues (all but the last row of the last (b,h)): load4's spill_ok
-  auto rows_safe = [&](int i0) __attribute__((always_inline)) { return (bh == BH - 1) ? N - 1 - i0 : TI; };
 
   stage_keys(Vt, v_bh, vs.sn, nj, nj32);
   WideTile ta;
@@ -385,7 +345,7 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
     if (p < 4) {
-      ta.v[p] = load_wide_slot(wm, p, a_bh + (int64_t)i0 * N, N, rows_valid, nj, rows_safe(i0));
+      ta.v[p] = load_wide_slot(wm, p, a_bh + (int64_t)i0 * N, N, rows_valid, nj);
     } else if (p == 4) {
       rr = f32x4{0.f, 0.f, 0.f, 0.f};
       if (srow < rows_valid) rr = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(i0 + srow) * rs.sn + (sc << 2));
@@ -414,42 +374,44 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
       *reinterpret_cast<f32x4*>(St + swz64(srow, sc)) = s;
       store_small_T(StT, srow, sc, s);
       store_wide_T(WtT, wm, ta);
-      // cam_attn of the PREVIOUS tile: whole rows as 16-B stores from its LDS image
-      if (it > 0) store_wide_global(Ct, wm, ca_bh + (int64_t)(i0 - TI) * N, N, TI, nj, j0 + nj == N);
     }
     TE_MARK(2);
     __syncthreads();
     TE_MARK(3);
-    // G = S v^T for key block `wave`; the six loads of the next tile go out one per MFMA group
-    f32x16 gacc;
-    zero16(gacc);
-    const int jl = wave * 32 + lr;
-    const bool more = it + 1 < ntiles;
-    row_product32(gacc, wave < njb, St, lr, Vt, jl, kh, [&](int kg) __attribute__((always_inline)) {
-      if (more && kg < 6) fetch_part(it + 1, kg);
-    });
+    if (it + 1 < ntiles) {
+#pragma unroll
+      for (int p = 0; p < 6; ++p) fetch_part(it + 1, p);
+    }
     TE_MARK(4);
-    if constexpr (MODE == RULE) {          // cam_attn = attn . G: the block's sixteen attention values in one LDS round trip
-      if (wave < njb) {
+    // G = S v^T for key block `wave`; cam_attn = attn . G straight from the accumulators
+    if (wave < njb) {
+      f32x16 gacc;
+      zero16(gacc);
+      const int jl = wave * 32 + lr;
+      row_product32(gacc, true, St, lr, Vt, jl, kh, [](int) {});
+      if constexpr (MODE == RULE) {        // the block's sixteen attention values in one LDS round trip
         float av[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) av[e] = atT(WtT, jl, crow(e, kh));
 #pragma unroll
         for (int e = 0; e < 16; ++e) gacc[e] = (av[e] * gacc[e]) * scale;
       }
-    }
-    if (wave < njb) {                      // stage the block for the coalesced row stores of the next trip
+      float* dst = ca_bh + (int64_t)(i0 + 4 * kh) * N + jl;
+      const int nrow = N - i0 - 4 * kh;                       // rows of this half-wave's block that exist
+      if (jl < nj) {
+        if (nrow >= 28) {                                     // every row of the block exists: plain stores
 #pragma unroll
-      for (int e = 0; e < 16; ++e) Ct[swzw(crow(e, kh), jl >> 2) + (jl & 3)] = gacc[e];
+          for (int e = 0; e < 16; ++e) dst[(int64_t)((e & 3) + 8 * (e >> 2)) * N] = gacc[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if ((e & 3) + 8 * (e >> 2) < nrow) dst[(int64_t)((e & 3) + 8 * (e >> 2)) * N] = gacc[e];
+        }
+      }
     }
     TE_MARK(5);
     col_product(accv, WtT, StT, wave, lr, kh, 2 * njb, [](int) {});
     TE_MARK(6);
-  }
-  __syncthreads();
-  {
-    const int i0 = (ntiles - 1) * TI;
-    store_wide_global(Ct, wm, ca_bh + (int64_t)i0 * N, N, min(TI, N - i0), nj, j0 + nj == N);
   }
   float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
   col_epilogue<MODE == BWD, false>(accv, Vt, v_bh, vs.sn, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
@@ -470,11 +432,11 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   long long tprev = prof ? clock64() : 0;
-  float* KtT = smem;                   // [64][256]  k of this group TRANSPOSED (row-side B operand, K = key contiguous)
-  float* QtT = KtT + NJMAX * 64;       // [64][TI]   q tile transposed (column-side B operand)
-  float* Wt = QtT + 64 * TI;           // [TI][256]  the S tile (row-side A operand, K = key contiguous)
-  float* WtT = Wt + TI * WLD;          // [256][TI]  the S tile transposed (column-side A operand)
-  float* Pt = WtT + NJMAX * TI;        // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
+  float* KtT = smem;                   // [64][JG]   k of this group TRANSPOSED (row-side B operand, K = key contiguous)
+  float* QtT = KtT + JG * 64;          // [64][TI]   q tile transposed (column-side B operand)
+  float* Wt = QtT + 64 * TI;           // [TI][JG]   the S tile (row-side A operand, K = key contiguous)
+  float* WtT = Wt + TI * JG;           // [JG][TI]   the S tile transposed (column-side A operand)
+  float* Pt = WtT + JG * TI;           // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -486,18 +448,17 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const int ntiles = (N + TI - 1) / TI;
   const WideMap wm = wide_map(nj32);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
-  auto rows_safe = [&](int i0) __attribute__((always_inline)) { return (bh == BH - 1) ? N - 1 - i0 : TI; };
 
-  stage_keys_T(KtT, k_bh, ks.sn, nj, nj32);
+  stage_keys_T(KtT, k_bh, ks.sn, nj, nj32, JG);
   WideTile tr, tz;
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
   // part p = 0..8 of tile `it`: the four float4 slots of the R tile, of the Z tile, then the q float4
   auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
     if (p < 4) {
-      tr.v[p] = load_wide_slot(wm, p, r_bh + (int64_t)i0 * N, N, rows_valid, nj, rows_safe(i0));
+      tr.v[p] = load_wide_slot(wm, p, r_bh + (int64_t)i0 * N, N, rows_valid, nj);
     } else if (p < 8) {
-      tz.v[p - 4] = load_wide_slot(wm, p - 4, z_bh + (int64_t)i0 * N, N, rows_valid, nj, rows_safe(i0));
+      tz.v[p - 4] = load_wide_slot(wm, p - 4, z_bh + (int64_t)i0 * N, N, rows_valid, nj);
     } else {
       qq = f32x4{0.f, 0.f, 0.f, 0.f};
       if (srow < rows_valid) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * qs.sn + (sc << 2));
@@ -551,7 +512,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
           for (int e = 0; e < 4; ++e) tr.v[r][e] = (tz.v[r][e] * (tr.v[r][e] - rd)) * scale;   // zero-filled: 0
         }
     }
-    store_wide(Wt, wm, tr);
+    store_wide(Wt, wm, tr, JG);
     store_wide_T(WtT, wm, tr);
     store_small_T(QtT, srow, sc, qq);
     TE_MARK(2);
@@ -570,7 +531,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
       // cam_q block (ib, db) = S[16 x keys] k[keys x 16]
       f32x4 cq = {0.f, 0.f, 0.f, 0.f};
       const int arow = ib * 16 + l15, dcol = db * 16 + l15;
-      row_product16(cq, Wt, arow, KtT, dcol, kq, nj32);
+      row_product16(cq, Wt, arow, KtT, dcol, kq, nj32, JG);
       TE_MARK(5);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -641,7 +602,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
   const int ntiles = (N + TI - 1) / TI;
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
   stage_keys(Kt, k_bh, sn, nj, nj32);
-  stage_keys_T(VtT, v_bh, sn, nj, nj32);
+  stage_keys_T(VtT, v_bh, sn, nj, nj32, WLD);
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int it) __attribute__((always_inline)) {
     const int i0 = it * TI;
@@ -732,7 +693,7 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
       // out block (ib, db) = P[16 x keys] v[keys x 16]
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
       const int arow = ib * 16 + l15, dcol = db * 16 + l15;
-      row_product16(o, Wt, arow, VtT, dcol, kq, nj32);
+      row_product16(o, Wt, arow, VtT, dcol, kq, nj32, WLD);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int il = ib * 16 + kq * 4 + r;
@@ -742,14 +703,24 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
   }
 }
 
-constexpr size_t kLdsAv = (size_t)(NJMAX * 64 + 2 * TI * 64 + NJMAX * TI + TI * WLD) * sizeof(float);     // 144 KB
-constexpr size_t kLdsQk = (size_t)(NJMAX * 64 + TI * 64 + TI * WLD + NJMAX * TI) * sizeof(float);        // 136 KB
-constexpr size_t kLdsQkBwd = kLdsQk + (size_t)TI * 64 * sizeof(float);                                    // + rowdot scratch
+inline size_t lds_av(int jg) { return (size_t)(jg * 64 + 2 * TI * 64 + jg * TI) * sizeof(float); }      // 64 KB at 128 keys
+inline size_t lds_qk(int jg, bool bwd) {                                                              // 72 KB at 128 keys
+  return (size_t)(jg * 64 + TI * 64 + 2 * TI * jg + (bwd ? TI * 64 : 0)) * sizeof(float);
+}
 constexpr size_t kLdsFwd = (size_t)(NJF * 64 + 64 * WLD + TI * 64 + TI * WLD) * sizeof(float);   // 160 KB: all of a CU's LDS
 
-inline void groups_for(int64_t N, int& ng, int& jg) {
-  ng = (int)((N + NJMAX - 1) / NJMAX);
-  jg = (int)(((N + ng - 1) / ng + 31) & ~(int64_t)31);      // equal groups, rounded up to whole 32-key blocks
+// Keys per workgroup.  128 keys keep a workgroup's LDS at 64-72 KB, i.e. TWO workgroups (16 waves) per CU: while one
+// forms its S tile or waits for its loads the other one runs MFMAs -- with one 104-136 KB workgroup per CU the memory
+// pipe and the matrix pipe take turns.  TE_ATTN_JG = 128 | 192 | 256 pins the group size (tuning).
+inline void groups_for(int64_t N, int& ng, int& jg, int jmax = 0) {
+  static const int pinned = [] {
+    const char* e = getenv("TE_ATTN_JG");
+    const int v = e ? atoi(e) : 0;
+    return (v == 128 || v == 192 || v == 256) ? v : 0;
+  }();
+  if (jmax == 0) jmax = pinned ? pinned : 128;
+  ng = (int)((N + jmax - 1) / jmax);
+  jg = (int)(((N + ng - 1) / ng + 63) & ~(int64_t)63);      // equal groups, whole 64-key units (the LDS row stride)
 }
 
 template <typename K>
@@ -787,8 +758,8 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
-  allow_lds(av_rule_kernel<RULE>, kLdsAv);
-  av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLdsAv, stream>>>(
+  allow_lds(av_rule_kernel<RULE>, lds_av(256));
+  av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), lds_av(jg), stream>>>(
       R, Strided{r_sb, r_sh, r_sn}, Z, Strided{z_sb, z_sh, z_sn}, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v,
       Strided{cv_sb, cv_sh, cv_sn}, (int)H, (int)N, BH, jg, scale, g_prof);
   return TE_OK;
@@ -801,9 +772,9 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
-  allow_lds(qk_rule_kernel<RULE>, kLdsQk);
+  allow_lds(qk_rule_kernel<RULE>, lds_qk(256, false));
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
-  qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), kLdsQk, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
+  qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), lds_qk(jg, false), stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
                                                                               cks, qpart, (int)H, (int)N, BH, jg, ng,
                                                                               scale, g_prof ? g_prof + 64 : nullptr);
   if (ng > 1) {
@@ -849,16 +820,16 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
   const Strided heads{N * C, 64, C};            // [B,N,C] seen as [B,H,N,64]
   const Strided fused{N * 3 * C, 64, 3 * C};    // one of q / k / v inside [B,N,3C]
   int ng, jg;
-  groups_for(N, ng, jg);                        // N <= 224: one group
+  groups_for(N, ng, jg, 256);                   // N <= 224: one group (the softmax backward needs every key of a row)
   // d_attn = d_out v^T ; d_v = attn^T d_out
-  allow_lds(av_rule_kernel<BWD>, kLdsAv);
-  av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsAv, stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
+  allow_lds(av_rule_kernel<BWD>, lds_av(256));
+  av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), lds_av(jg), stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
                                                                       qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
                                                                       (int)H, (int)N, BH, jg, 1.0f, nullptr);
   if (need_qk) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q
-    allow_lds(qk_rule_kernel<BWD>, kLdsQkBwd);
-    qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), kLdsQkBwd, stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
+    allow_lds(qk_rule_kernel<BWD>, lds_qk(256, true));
+    qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), lds_qk(jg, true), stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
                                                                            d_qkv, fused, d_qkv + C, fused, nullptr,
                                                                            (int)H, (int)N, BH, jg, 1, scale, nullptr);
   }
