@@ -709,16 +709,17 @@ inline size_t lds_qk(int jg, bool bwd) {                                        
 }
 constexpr size_t kLdsFwd = (size_t)(NJF * 64 + 64 * WLD + TI * 64 + TI * WLD) * sizeof(float);   // 160 KB: all of a CU's LDS
 
-// Keys per workgroup.  128 keys keep a workgroup's LDS at 64-72 KB, i.e. TWO workgroups (16 waves) per CU: while one
-// forms its S tile or waits for its loads the other one runs MFMAs -- with one 104-136 KB workgroup per CU the memory
-// pipe and the matrix pipe take turns.  TE_ATTN_JG = 128 | 192 | 256 pins the group size (tuning).
+// Keys per workgroup: 256 (one 112-136 KB workgroup per CU).  Groups of 128 keys (64-72 KB: two workgroups per CU) were
+// measured SLOWER on the MI355X (ViT-B B=64: AV 202 vs 170 us, QK 319 vs 257 us; N = 577 / 512 alike): the time of a
+// row tile is dominated by per-tile costs that do not shrink with the tile, so halving the keys
+// doubles them.  TE_ATTN_JG = 128 | 192 | 256 pins the group size (tuning).
 inline void groups_for(int64_t N, int& ng, int& jg, int jmax = 0) {
   static const int pinned = [] {
     const char* e = getenv("TE_ATTN_JG");
     const int v = e ? atoi(e) : 0;
     return (v == 128 || v == 192 || v == 256) ? v : 0;
   }();
-  if (jmax == 0) jmax = pinned ? pinned : 128;
+  if (jmax == 0) jmax = pinned ? pinned : 256;
   ng = (int)((N + jmax - 1) / jmax);
   jg = (int)(((N + ng - 1) / ng + 63) & ~(int64_t)63);      // equal groups, whole 64-key units (the LDS row stride)
 }
