@@ -75,9 +75,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-maps", type=int, default=5, help="timed maps of the all-cores cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="micro-batches in flight on separate HIP streams")
-    ap.add_argument("--graph", choices=["on", "off"], default="on",
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay each step from a HIP graph (one eager step inside the timed region carries the "
-                         "per-kernel HIP events of the roofline)")
+                         "per-kernel HIP events of the roofline); auto = on for the headline configuration, off for "
+                         "ViT-L/384 and BERT-512 (a captured step pins a second copy of the 40-120 GB of activations)")
     ap.add_argument("--tuned-gemms", choices=["on", "off", "tune"], default="on",
                     help="stock fp32 GEMMs of forward/backward selected by PyTorch TunableOp from the committed results "
                          "file (on), PyTorch's default heuristic (off), or tune now and write gpurun_out/ (tune)")
@@ -479,7 +480,8 @@ def main():
     # The graph is captured BEFORE the process group exists: RCCL's proxy / watchdog threads touch the HIP runtime on
     # their own and must never meet an open capture; replay afterwards is an ordinary launch.
     graphed = None
-    if args.graph == "on" and args.inflight == 1 and args.streams == 1:
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.config == "vit_b16_224")
+    if use_graph and args.inflight == 1 and args.streams == 1:
         try:
             graphed = GraphedCall(wl.eager, wl.inputs)
             log("HIP graph of one step captured")

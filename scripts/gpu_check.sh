@@ -10,6 +10,12 @@ mkdir -p gpurun_out; rm -f gpurun_out/parity_report.jsonl; rm -rf gpurun_out/pro
     python "$OLDPWD/bench.py" --cpu-baseline off > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof_bench.err" )
 rm -f gpurun_out/prof/*agent_info* gpurun_out/prof/*kernel_trace*
 ( timeout 300 python bench.py --producers fused --cpu-baseline off > gpurun_out/bench_b64_fused.json 2> gpurun_out/bench_b64_fused.err )
+for cfg in vit_l16_384 bert_base_512; do
+  ( timeout 500 python bench.py --config $cfg --steps 3 --warmup 1 --cpu-maps 2 > gpurun_out/bench_$cfg.json 2> gpurun_out/bench_$cfg.err )
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d "$OLDPWD/gpurun_out/prof_$cfg" -o bench -- \
+      python "$OLDPWD/bench.py" --config $cfg --steps 2 --warmup 1 --cpu-baseline off > /dev/null 2> "$OLDPWD/gpurun_out/prof_$cfg.err" )
+  rm -f gpurun_out/prof_$cfg/*agent_info* gpurun_out/prof_$cfg/*kernel_trace*
+done
 ( timeout 200 python scripts/stream_kernels_bw.py 2>&1 | tail -12 ) > gpurun_out/stream_kernels_bw.log
 ( TE_HEADMEAN_VARIANT=0 timeout 100 python scripts/stream_kernels_bw.py --only headmean 2>&1 | tail -3 ) >> gpurun_out/stream_kernels_bw.log
 ( for impl in rules tiles; do echo "TE_ATTN_IMPL=$impl"; for shape in "64 12 197" "32 16 577" "32 12 512"; do
@@ -20,6 +26,7 @@ echo "=== tests ==="; cat gpurun_out/tests_full.log
 echo "=== smoke ==="; cat gpurun_out/smoke.log
 echo "=== bench ==="; cat gpurun_out/bench_b64.json; tail -25 gpurun_out/bench_b64.err
 echo "=== bench, fused producers ==="; cut -c1-330 gpurun_out/bench_b64_fused.json; tail -4 gpurun_out/bench_b64_fused.err
+for cfg in vit_l16_384 bert_base_512; do echo "=== bench $cfg ==="; cut -c1-300 gpurun_out/bench_$cfg.json; tail -3 gpurun_out/bench_$cfg.err; done
 echo "=== rocprof top kernels ==="; head -14 gpurun_out/prof/bench_kernel_stats.csv | cut -d, -f1-4
 echo "=== streaming kernels ==="; cat gpurun_out/stream_kernels_bw.log
 echo "=== attention rules ==="; cat gpurun_out/attn_bench.log

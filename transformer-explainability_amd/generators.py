@@ -231,6 +231,7 @@ class GraphedCall:
                 fn(*self.static_in)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()               # the capture allocates from its own pool: hand the warm-up's blocks back
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = fn(*self.static_in)
