@@ -165,6 +165,37 @@ __device__ __forceinline__ void load_kn_tile_fast(const float* __restrict__ M, i
   for (int i = 0; i < BN / 32; ++i) reg[i] = *reinterpret_cast<const f32x4*>(p + (int64_t)i * RPI * Nn);
 }
 
+// Direct-to-LDS staging (global_load_lds_dwordx4: 64 lanes x 16 B land at a wave-uniform LDS base + lane * 16, no VGPR
+// round trip, no ds_write): the LDS images above are lane-linear in the thread index (float4 slot idx = t + 256 i sits
+// at float offset 4 idx), so the XOR swizzle of the K-contiguous tile moves to the SOURCE address -- lane (row, physical
+// chunk pc) fetches logical chunk pc ^ ((row >> 1) & 7) of its row; the eight lanes of a row still read one 128-B line.
+__device__ __forceinline__ void glds16(const float* __restrict__ src, float* __restrict__ lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int ROWS>
+__device__ __forceinline__ void glds_rows_tile(float* __restrict__ lds, const float* __restrict__ M, int64_t K,
+                                               int64_t row0, int64_t k0, int wave_base) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int idx = wave_base + lane + i * kThreads;
+    const int row = idx >> 3, lc = (idx & 7) ^ ((row >> 1) & 7);
+    glds16(M + (row0 + row) * K + k0 + (lc << 2), lds + (wave_base + i * kThreads) * 4);
+  }
+}
+template <int BN>
+__device__ __forceinline__ void glds_kn_tile(float* __restrict__ lds, const float* __restrict__ M, int64_t Nn, int64_t k0,
+                                             int64_t n0, int wave_base) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) {
+    const int idx = wave_base + lane + i * kThreads;
+    const int kk = idx / (BN / 4), c4 = idx % (BN / 4);
+    glds16(M + (k0 + kk) * Nn + n0 + (c4 << 2), lds + (wave_base + i * kThreads) * 4);
+  }
+}
+
 // K-loop schedule shared by both kernels (one K-step = 4 k-groups of 8):
 //
 //     k-group 0 : MFMAs on fragments read during the PREVIOUS step's last group   | reads of group 1
@@ -526,7 +557,7 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k1_kernel(
 //             products P = S W+, N = S W-, epilogue out = x (P + N) - l_b P - h_b N with x read from / out written
 //             to the NCHW image through the patch geometry (no im2col copy); l_b, h_b = sample b's pixel min / max
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool SWAP, bool ACCUM, int BM, int BN>
+template <int MODE, bool SWAP, bool ACCUM, int BM, int BN, bool GLDS = false>
 __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
     const float* __restrict__ S, const float* __restrict__ W, const float* __restrict__ X,
     float* __restrict__ out, int64_t T, int64_t K, int64_t Nn, int nbn, int ntiles, float scale, TeZbGeom zb) {
@@ -597,6 +628,41 @@ __global__ __launch_bounds__(kThreads, 2) void linear_k2_kernel(
 
   auto k_loop = [&](auto fast_tag) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_tag)::value;
+    if constexpr (FAST && GLDS) {
+      // interior tiles, direct-to-LDS staging: the next K-step's tiles are requested at the top of the step (its
+      // stage was released by the barrier that ended the previous step) and are waited for by the step's one barrier
+      const int wave_base = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63);
+      auto stage = [&](int st, int kt) __attribute__((always_inline)) {
+        glds_rows_tile<BM>(smem + st * STAGE, S, K, tc.row0, (int64_t)kt * BK, wave_base);
+        glds_kn_tile<BN>(smem + st * STAGE + A_SZ, W, Nn, (int64_t)kt * BK, tc.col0, wave_base);
+      };
+      stage(0, 0);
+      __syncthreads();
+      Frag f0, f1;
+      read_frag(f0, 0, 0);
+      int cur = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) stage(cur ^ 1, kt + 1);
+        read_frag(f1, cur, 1);
+        mma_group(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f0, cur, 2);
+        mma_group(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f1, cur, 3);
+        mma_group(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          __syncthreads();
+          read_frag(f0, cur ^ 1, 0);
+        }
+        mma_group(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+      }
+      return;
+    }
     f32x4 ra[BM / 32], rb[BN / 32];
     auto load_next = [&](int kt) __attribute__((always_inline)) {
       if constexpr (FAST) {
@@ -821,6 +887,19 @@ inline void launch_k2(const float* S, const float* W, const float* X, float* out
   const int nbn = (int)te_ceil_div(in_f, BN);
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k2_lds<BM, BN>();
+  if constexpr (MODE == 0 && !SWAP && !ACCUM) {
+    // TE_CPASS_GLDS=1: direct-to-LDS staging of the interior tiles (tuning study; see glds16)
+    static const bool glds = [] {
+      const char* e = getenv("TE_CPASS_GLDS");
+      return e && atoi(e) != 0;
+    }();
+    if (glds) {
+      allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN, true>, lds);
+      linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN, true><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
+          S, W, X, out, T, out_f, in_f, nbn, ntiles, scale, zb);
+      return;
+    }
+  }
   allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN>, lds);
   linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
       S, W, X, out, T, out_f, in_f, nbn, ntiles, scale, zb);
