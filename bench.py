@@ -185,6 +185,8 @@ KERNEL_GROUPS = {
     "add_deferred": ("add_deferred_kernel + add_factors_kernel", "Add.relprop (one pass; rescale applied by the "
                                                                  "consumers), layers_ours.py:97-120"),
     "add": ("add_sums_kernel + add_apply_kernel", "Add.relprop, layers_ours.py:97-120"),
+    "add_bcast_mask_deferred": ("addb_sums_kernel<store> + addb_finalize_kernel", "Add.relprop with the BERT mask operand, "
+                                "one pass; rescale applied in the QK rule, BERT.py:386-388"),
     "add_bcast_mask": ("addb_sums + addb_finalize + addb_apply", "Add.relprop with the BERT mask operand, BERT.py:386-388"),
     "clone": ("clone_kernel / clone_scaled_kernel", "Clone.relprop, layers_ours.py:151-169"),
     "headmean": ("headmean_flat_kernel", "mean_h max(grad * attn_cam, 0), ViT_LRP.py:359-366"),

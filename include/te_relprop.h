@@ -160,6 +160,17 @@ int te_matmul_relprop_qk_fwd_f32(const float* R_nn,
                                  float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
                                  int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
                                  void* ws, size_t ws_bytes, te_stream_t stream);
+/* te_matmul_relprop_qk_fwd_f32 whose relevance operand carries a DEFERRED per-sample factor: sample b's R_nn enters as
+ * R_nn[b] * r_scale[b * r_scale_stride] -- the consumer side of te_add_bcast_relprop_deferred_f32 (BERT.py:386-393).
+ * r_scale == NULL: plain.  One-pass kernels only (head dim 64): TE_ERR_UNSUPPORTED otherwise. */
+int te_matmul_relprop_qk_fwd_scaled_f32(const float* R_nn, const float* r_scale, int64_t r_scale_stride,
+                                        const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                                        const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                        const float* Z,
+                                        float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
+                                        float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
+                                        int64_t B, int64_t H, int64_t N, int64_t D, float out_scale, int variant,
+                                        void* ws, size_t ws_bytes, te_stream_t stream);
 int te_matmul_relprop_qk_f32(const float* R_nn,
                              const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
                              const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
@@ -199,6 +210,13 @@ size_t te_add_bcast_relprop_workspace_bytes(int64_t B, int64_t H, int64_t N);
 int te_add_bcast_relprop_f32(const float* R, const float* X0, const float* mask, float* out0,
                              float* out1, int64_t B, int64_t H, int64_t N, int variant,
                              void* ws, size_t ws_bytes, te_stream_t stream);
+
+/* The same rule (variant ours) with the rescale deferred: ONE pass over R and X0 writes a = X0.S unscaled and
+ * fac [B,2] = {fa, fb}; out1 [B,N] (optional) is written scaled.  a * fa is bitwise te_add_bcast_relprop_f32's out0;
+ * the consumer is te_matmul_relprop_qk_fwd_scaled_f32.  Workspace: te_add_bcast_relprop_workspace_bytes. */
+int te_add_bcast_relprop_deferred_f32(const float* R, const float* X0, const float* mask, float* a, float* out1,
+                                      float* fac, int64_t B, int64_t H, int64_t N,
+                                      void* ws, size_t ws_bytes, te_stream_t stream);
 
 /* ---- a6  Clone.relprop --------------------------------------------------------------------------
  * replaces modules/layers_ours.py:151-169.  out = X .(sd(R0,X) + sd(R1,X) [+ sd(R2,X)]); R2 may be

@@ -31,7 +31,7 @@ def matmul_relprop_av(R, attn, v, out_scale=1.0, cam_v_out=None, variant="ours",
 
 
 def matmul_relprop_qk(R, q, k, out_scale=1.0, cam_q_out=None, cam_k_out=None, variant="ours", z=None):
-    c_q, c_k = O.einsum_qk_relprop(R, q, k)
+    c_q, c_k = O.einsum_qk_relprop(_plain(R), q, k)
     c_q = c_q * out_scale
     c_k = c_k * out_scale
     if cam_q_out is not None:
@@ -45,7 +45,7 @@ def matmul_relprop_qk(R, q, k, out_scale=1.0, cam_q_out=None, cam_k_out=None, va
 
 def add_relprop(R, X0, X1, variant="ours", deferred=False):
     a, b = O.add_relprop(R, X0, X1, variant)
-    if deferred and variant == "ours":
+    if deferred and variant == "ours" and a.shape == b.shape:
         # same host-side contract as the device op: (tensor, per-sample factor) pairs.  The oracle has already applied
         # the rescale, so the factor is an exact 1 (x * 1.0f is the identity in fp32).
         from transformer_explainability_amd import ops

@@ -369,6 +369,30 @@ def test_add_deferred_equals_two_pass(shape):
     assert torch.is_tensor(la) and torch.is_tensor(lb)
 
 
+@pytest.mark.parametrize("B,H,N", [(1, 3, 7), (2, 12, 128), (3, 4, 300), (4, 12, 512)])
+def test_add_bcast_mask_deferred(B, H, N):
+    """Deferred broadcast-mask Add (one pass, factor handed to the QK rule) == the two-pass rule once the factor is
+    applied, bitwise; the QK rule taking the factor in its S tile == the QK rule on the materialised operand, bitwise."""
+    from transformer_explainability_amd import ops
+    d = dev()
+    X0 = rnd((B, H, N, N), 81).to(d)
+    mask = torch.zeros(B, 1, 1, N)
+    mask[::2, ..., N - max(1, N // 4):] = -10000.0
+    mask = mask.to(d)
+    R = rnd((B, H, N, N), 82, 0.01).to(d)
+    a, b1 = ops.add_relprop(R, X0, mask, variant="ours")
+    da, db1 = ops.add_relprop(R, X0, mask, variant="ours", deferred=True)
+    assert isinstance(da, ops.Deferred)
+    assert torch.equal(da.materialise(), a), float((da.materialise() - a).abs().max())
+    assert torch.equal(db1, b1)
+    D = 64
+    q, k = rnd((B, H, N, D), 83).to(d), rnd((B, H, N, D), 84).to(d)
+    z = q @ k.transpose(-1, -2)
+    cq, ck = ops.matmul_relprop_qk(da, q, k, out_scale=0.5, z=z)
+    rq, rk = ops.matmul_relprop_qk(a, q, k, out_scale=0.5, z=z)
+    assert torch.equal(cq, rq) and torch.equal(ck, rk)
+
+
 @pytest.mark.parametrize("B,N,in_f,out_f", [(3, 197, 768, 768), (2, 197, 3072, 768), (64, 1, 768, 768), (2, 50, 64, 192),
                                             (5, 33, 24, 40)])
 def test_linear_with_deferred_relevance(B, N, in_f, out_f):

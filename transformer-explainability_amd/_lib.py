@@ -52,6 +52,9 @@ SIGNATURES = {
     "te_attention_backward_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "te_matmul_relprop_qk_fwd_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
                                           _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
+    "te_matmul_relprop_qk_fwd_scaled_f32": (_I, [_P, _P, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64,
+                                                 _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P,
+                                                 _SZ, _P]),
     "te_matmul_relprop_qk_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64,
                                       _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_add_relprop_workspace_bytes": (_SZ, [_I64, _I64]),
@@ -60,6 +63,7 @@ SIGNATURES = {
     "te_add_relprop_deferred_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     "te_add_bcast_relprop_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_add_bcast_relprop_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _SZ, _P]),
+    "te_add_bcast_relprop_deferred_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     "te_clone_relprop_f32": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     "te_clone_relprop_scaled_f32": (_I, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _P]),
     "te_index_select_relprop_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _P]),

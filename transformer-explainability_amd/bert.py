@@ -137,7 +137,8 @@ def make_bert_module(L):
             if getattr(self, "_stop_after_attn_cam", False):   # Generator(prune=True): nothing below is read
                 raise L.StopRelprop()
             if self.attention_mask is not None:
-                cam1, _ = self.add.relprop(cam1, **kwargs)                          # BERT.py:386-388
+                # (deferred: the Add's per-sample rescale rides with cam1 into the QK rule's S tile)
+                cam1, _ = self.add.relprop(cam1, deferred=True, **kwargs)           # BERT.py:386-388
             ops.matmul_relprop_qk(cam1, q, kt.transpose(-1, -2), out_scale=0.5, cam_q_out=as_heads(rq),
                                   cam_k_out=as_heads(rk), variant=var, z=getattr(self.matmul1, "Y", None))
             rq = self.query.relprop(rq, **kwargs)

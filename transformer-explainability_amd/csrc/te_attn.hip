@@ -25,7 +25,8 @@ bool qk_supported(int64_t N, int64_t D);
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
               const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb,
               int64_t cq_sh, int64_t cq_sn, float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
-              int64_t B, int64_t H, int64_t N, int64_t D, float scale, float* ws, hipStream_t stream);
+              int64_t B, int64_t H, int64_t N, int64_t D, float scale, float* ws, const float* r_scale,
+              int64_t r_scale_stride, hipStream_t stream);
 }  // namespace te_attn_mfma
 
 namespace {
@@ -223,6 +224,19 @@ extern "C" int te_matmul_relprop_qk_fwd_f32(const float* R_nn, const float* q, i
                                             int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N,
                                             int64_t D, float out_scale, int variant, void* ws, size_t ws_bytes,
                                             te_stream_t stream_) {
+  return te_matmul_relprop_qk_fwd_scaled_f32(R_nn, nullptr, 0, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb,
+                                             cq_sh, cq_sn, cam_k, ck_sb, ck_sh, ck_sn, B, H, N, D, out_scale, variant, ws,
+                                             ws_bytes, stream_);
+}
+
+extern "C" int te_matmul_relprop_qk_fwd_scaled_f32(const float* R_nn, const float* r_scale, int64_t r_scale_stride,
+                                                   const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                                                   const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                                   const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh,
+                                                   int64_t cq_sn, float* cam_k, int64_t ck_sb, int64_t ck_sh,
+                                                   int64_t ck_sn, int64_t B, int64_t H, int64_t N, int64_t D,
+                                                   float out_scale, int variant, void* ws, size_t ws_bytes,
+                                                   te_stream_t stream_) {
   if (!R_nn || !q || !k || !cam_q || !cam_k || B <= 0 || H <= 0 || N <= 0 || D <= 0) return TE_ERR_INVALID_ARG;
   if (!strides_ok(q_sb, q_sh, q_sn) || !strides_ok(k_sb, k_sh, k_sn) || !strides_ok(cq_sb, cq_sh, cq_sn) ||
       !strides_ok(ck_sb, ck_sh, ck_sn))
@@ -232,11 +246,13 @@ extern "C" int te_matmul_relprop_qk_fwd_f32(const float* R_nn, const float* q, i
   float* S = (float*)ws;
   if (!(variant & TE_IMPL_SIMPLE) && te_attn_mfma::qk_supported(N, D)) {
     int rc = te_attn_mfma::qk_launch(R_nn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn,
-                                     cam_k, ck_sb, ck_sh, ck_sn, B, H, N, D, out_scale, S, stream);
+                                     cam_k, ck_sb, ck_sh, ck_sn, B, H, N, D, out_scale, S, r_scale, r_scale_stride,
+                                     stream);
     if (rc != TE_OK) return rc;
     TE_RETURN_IF_LAUNCH_FAILED();
     return TE_OK;
   }
+  if (r_scale) return TE_ERR_UNSUPPORTED;        // the simple kernels take a plain relevance operand
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
   const int64_t nd = B * H * N * D, nn = B * H * N * N;
   dim3 blk(kThreads);

@@ -34,7 +34,7 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
               int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
               float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
-              float* qpart, hipStream_t stream);
+              float* qpart, const float* r_scale, int64_t r_scale_stride, hipStream_t stream);
 }  // namespace te_attn_rules
 
 namespace te_attn_mfma {
@@ -541,7 +541,7 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k,
               int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh,
               int64_t cq_sn, float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N,
-              int64_t D, float scale, float* ws, hipStream_t stream) {
+              int64_t D, float scale, float* ws, const float* r_scale, int64_t r_scale_stride, hipStream_t stream) {
   if (D != TS) return TE_ERR_UNSUPPORTED;
   const int BH = (int)(B * H);
   const int nt = (int)((N + TS - 1) / TS);
@@ -557,7 +557,8 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
     // (the per-group cam_q partials of N > 256 live in the S region of the workspace, which this path never writes:
     //  ngroups * 64 <= N whenever ngroups > 1)
     return te_attn_rules::qk_launch(Rnn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn, cam_k,
-                                    ck_sb, ck_sh, ck_sn, B, H, N, scale, wsS, stream);
+                                    ck_sb, ck_sh, ck_sn, B, H, N, scale, wsS, r_scale, r_scale_stride, stream);
+  if (r_scale) return TE_ERR_UNSUPPORTED;        // only the one-pass kernel takes the deferred factor
   qk_row_kernel<<<grid, blk, 0, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, wsS, (int)H, (int)N, BH, scale);
   col_kernel<<<grid, blk, 0, stream>>>(wsS, q, qs, k, ks, cam_k, cks, (int)H, (int)N, BH, scale);
   return TE_OK;

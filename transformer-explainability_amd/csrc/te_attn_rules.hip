@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     const float* __restrict__ Rnn, const float* __restrict__ Z, const float* __restrict__ q, Strided qs,
     const float* __restrict__ k, Strided ks, float* __restrict__ cam_q, Strided cqs, float* __restrict__ cam_k,
     Strided cks, float* __restrict__ qpart, int H, int N, int BH, int JG, int ngroups, float scale,
-    long long* __restrict__ prof) {
+    long long* __restrict__ prof, const float* __restrict__ r_scale, int64_t r_scale_stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   long long tprev = prof ? clock64() : 0;
   float* KtT = smem;                   // [64][JG]   k of this group TRANSPOSED (row-side B operand, K = key contiguous)
@@ -477,6 +477,13 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     __syncthreads();
     TE_MARK(1);
     if constexpr (MODE == RULE) {
+      if (r_scale != nullptr) {            // deferred per-sample factor of the broadcast-mask Add (BERT.py:386-388)
+        const float f = r_scale[(int64_t)b * r_scale_stride];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tr.v[r][e] = tr.v[r][e] * f;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -769,7 +776,7 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
               int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
               float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
-              float* qpart, hipStream_t stream) {
+              float* qpart, const float* r_scale, int64_t r_scale_stride, hipStream_t stream) {
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
@@ -777,7 +784,8 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
   qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), lds_qk(jg, false), stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
                                                                               cks, qpart, (int)H, (int)N, BH, jg, ng,
-                                                                              scale, g_prof ? g_prof + 64 : nullptr);
+                                                                              scale, g_prof ? g_prof + 64 : nullptr, r_scale,
+                                                                              r_scale_stride);
   if (ng > 1) {
     const int64_t n4 = (int64_t)BH * N * 16;
     qk_finish_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(qpart, q, qs, cam_q, cqs, (int)H,
@@ -832,7 +840,8 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
     allow_lds(qk_rule_kernel<BWD>, lds_qk(256, true));
     qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), lds_qk(jg, true), stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
                                                                            d_qkv, fused, d_qkv + C, fused, nullptr,
-                                                                           (int)H, (int)N, BH, jg, 1, scale, nullptr);
+                                                                           (int)H, (int)N, BH, jg, 1, scale, nullptr, nullptr,
+                                                                           0);
   }
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;

@@ -225,9 +225,11 @@ __global__ __launch_bounds__(kThreads) void add_apply_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxColsPerThread = 8;  // N <= 2048
 
+// STORE: also write the unscaled a = X0 . S (deferred form: the per-sample factor goes to the consumer, the QK rule)
+template <bool STORE>
 __global__ __launch_bounds__(kThreads) void addb_sums_kernel(
     const float* __restrict__ R, const float* __restrict__ X0, const float* __restrict__ mask,
-    double* __restrict__ partial, int64_t rows, int64_t N, int64_t rows_per_block) {
+    double* __restrict__ partial, float* __restrict__ a_out, int64_t rows, int64_t N, int64_t rows_per_block) {
   __shared__ double smem[3 * (kThreads / 64)];
   const int64_t b = blockIdx.y;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -244,16 +246,30 @@ __global__ __launch_bounds__(kThreads) void addb_sums_kernel(
     mv[c] = (j < N) ? m[j] : 0.0f;
   }
   double sa = 0.0, sr = 0.0, dummy = 0.0;
-  for (int64_t row = r0; row < r1; ++row) {
+  float* ao = STORE ? a_out + b * rows * N : nullptr;
+  constexpr int RU = 4;       // rows in flight per thread: 2 RU loads per column slot issued before the first use
+  for (int64_t row = r0; row < r1; row += RU) {
 #pragma unroll
     for (int c = 0; c < kMaxColsPerThread; ++c) {
       const int64_t j = threadIdx.x + (int64_t)c * kThreads;
       if (j < N) {
-        const float rv = r[row * N + j], av = x0[row * N + j];
-        const float s = te_sd(rv, av + mv[c]);
-        sa += (double)(av * s);
-        sr += (double)rv;
-        csum[c] += (double)s;
+        float rv[RU], av[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const bool ok = row + u < r1;
+          rv[u] = ok ? r[(row + u) * N + j] : 0.0f;
+          av[u] = ok ? x0[(row + u) * N + j] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+          if (row + u < r1) {
+            const float s = te_sd(rv[u], av[u] + mv[c]);
+            const float a = av[u] * s;
+            if constexpr (STORE) ao[(row + u) * N + j] = a;
+            sa += (double)a;
+            sr += (double)rv[u];
+            csum[c] += (double)s;
+          }
       }
     }
   }
@@ -272,10 +288,12 @@ __global__ __launch_bounds__(kThreads) void addb_sums_kernel(
 
 // One block per sample: fold the partials, form b_j = mask_j * C1_j, the three sums and the factors.
 // fac[b] = {fa, fb}; bvec[b][j] = b_j (unscaled).
+// out1 (optional): the mask's relevance b_j * fb, written here in the deferred form (addb_apply_kernel writes it else)
 __global__ __launch_bounds__(kThreads) void addb_finalize_kernel(
     const double* __restrict__ partial, const float* __restrict__ mask, float* __restrict__ fac,
-    float* __restrict__ bvec, int64_t N, int nblk, int ours) {
+    float* __restrict__ bvec, int64_t N, int nblk, int ours, float* __restrict__ out1) {
   __shared__ double smem[3 * (kThreads / 64)];
+  __shared__ float fb_s;
   const int64_t b = blockIdx.x;
   const double* base = partial + b * nblk * (N + 2);
   double sb = 0.0, sa = 0.0, sr = 0.0;
@@ -296,6 +314,12 @@ __global__ __launch_bounds__(kThreads) void addb_finalize_kernel(
     if (ours) add_factors(sa, sb, sr, fa, fb);
     fac[b * 2 + 0] = fa;
     fac[b * 2 + 1] = fb;
+    fb_s = fb;
+  }
+  if (out1 != nullptr) {
+    __syncthreads();
+    const float fb = fb_s;
+    for (int64_t j = threadIdx.x; j < N; j += kThreads) out1[b * N + j] = bvec[b * N + j] * fb;
   }
 }
 
@@ -637,10 +661,35 @@ extern "C" int te_add_bcast_relprop_f32(const float* R, const float* X0, const f
   p += te_align_up((size_t)B * 2 * sizeof(float), 256);
   float* bvec = (float*)p;
   dim3 grid(nblk, (unsigned)B), block(kThreads);
-  addb_sums_kernel<<<grid, block, 0, stream>>>(R, X0, mask, partial, rows, N, rpb);
+  addb_sums_kernel<false><<<grid, block, 0, stream>>>(R, X0, mask, partial, nullptr, rows, N, rpb);
   addb_finalize_kernel<<<dim3((unsigned)B), block, 0, stream>>>(partial, mask, fac, bvec, N, nblk,
-                                                               var == TE_VARIANT_OURS ? 1 : 0);
+                                                               var == TE_VARIANT_OURS ? 1 : 0, nullptr);
   addb_apply_kernel<<<grid, block, 0, stream>>>(R, X0, mask, fac, bvec, out0, out1, rows, N, rpb);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// Deferred form (variant ours): ONE pass over R and X0 writes the unscaled a = X0 . S; fac [B,2] = {fa, fb} goes to the
+// consumer (te_matmul_relprop_qk_fwd_scaled_f32 multiplies the relevance operand by fa in its S tile); out1 [B,N]
+// (optional) = the mask's relevance, already scaled.  a * fa is bitwise te_add_bcast_relprop_f32's out0.
+extern "C" int te_add_bcast_relprop_deferred_f32(const float* R, const float* X0, const float* mask, float* a,
+                                                 float* out1, float* fac, int64_t B, int64_t H, int64_t N, void* ws,
+                                                 size_t ws_bytes, te_stream_t stream_) {
+  if (!R || !X0 || !mask || !a || !fac || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
+  if (N > (int64_t)kMaxColsPerThread * kThreads || B > 65535) return TE_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < te_add_bcast_relprop_workspace_bytes(B, H, N)) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t rows = H * N;
+  const int nblk = addb_blocks(B, rows);
+  const int64_t rpb = te_ceil_div(rows, nblk);
+  char* p = (char*)ws;
+  double* partial = (double*)p;
+  p += te_align_up((size_t)B * 64 * (N + 2) * sizeof(double), 256);
+  p += te_align_up((size_t)B * 2 * sizeof(float), 256);        // (the two-pass form's factor slot: unused here)
+  float* bvec = (float*)p;
+  dim3 grid(nblk, (unsigned)B), block(kThreads);
+  addb_sums_kernel<true><<<grid, block, 0, stream>>>(R, X0, mask, partial, a, rows, N, rpb);
+  addb_finalize_kernel<<<dim3((unsigned)B), block, 0, stream>>>(partial, mask, fac, bvec, N, nblk, 1, out1);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
@@ -653,8 +702,10 @@ extern "C" int te_clone_relprop_f32(const float* R0, const float* R1, const floa
   const bool vec = (n % 4 == 0) && te_aligned16(R0) && te_aligned16(R1) && te_aligned16(X) &&
                    te_aligned16(out) && (!R2 || te_aligned16(R2));
   const int vecw = vec ? 4 : 1;
-  int64_t blocks = te_ceil_div(n, (int64_t)kThreads * vecw * 2);
-  if (blocks > 4096) blocks = 4096;
+  // one float4 per thread (every block the same work, back-filled by the dispatcher) up to 64 K blocks; the
+  // grid-stride loop takes over beyond
+  int64_t blocks = te_ceil_div(n, (int64_t)kThreads * vecw);
+  if (blocks > 65535) blocks = 65535;
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks), block(kThreads);
   if (R2) {
@@ -678,8 +729,8 @@ extern "C" int te_clone_relprop_scaled_f32(const float* R0, const float* s0, int
   const bool vec = (n % 4 == 0) && te_aligned16(R0) && te_aligned16(R1) && te_aligned16(X) && te_aligned16(out) &&
                    (!R2 || te_aligned16(R2));
   const int vecw = vec ? 4 : 1;
-  int64_t bx = te_ceil_div(n, (int64_t)kThreads * vecw * 2);
-  const int64_t want = te_ceil_div(4096, B);
+  int64_t bx = te_ceil_div(n, (int64_t)kThreads * vecw);       // one float4 per thread
+  const int64_t want = te_ceil_div(65535, B);
   if (bx > want) bx = want;
   if (bx < 1) bx = 1;
   dim3 grid((unsigned)bx, (unsigned)B), block(kThreads);

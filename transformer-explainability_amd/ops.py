@@ -235,6 +235,7 @@ def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
     zc = _cached_z(z, (B, H, N, N))
     q, q_sb, q_sh, q_sn = _bhnd(q)
     k, k_sb, k_sh, k_sn = _bhnd(k)
+    R, r_scale = _split_deferred(R)
     R = _c(R)
     dev = R.device
     cam_q = cam_q_out if cam_q_out is not None else torch.empty((B, H, N, D), dtype=torch.float32, device=dev)
@@ -245,11 +246,15 @@ def matmul_relprop_qk(R: Tensor, q: Tensor, k: Tensor, out_scale: float = 1.0,
     with _on_device(R) as lib, _timed("attention_qk_rule", 4.0 * B * H * N * N * D,
                                       4.0 * B * H * (2 * N * N + 4 * N * D)):
         ws = _ws(lib.te_matmul_relprop_qk_workspace_bytes(B, H, N, D), R)
-        _lib.check(lib.te_matmul_relprop_qk_fwd_f32(
-            _ptr(R), _ptr(q), q_sb, q_sh, q_sn, _ptr(k), k_sb, k_sh, k_sn, _ptr(zc),
-            _ptr(cam_q), cq[0], cq[1], cq[2], _ptr(cam_k), ck[0], ck[1], ck[2],
-            B, H, N, D, float(out_scale), _variant(variant), _ptr(ws), ws.numel(), _stream(R)),
-            "te_matmul_relprop_qk_fwd_f32")
+        tail = (_ptr(q), q_sb, q_sh, q_sn, _ptr(k), k_sb, k_sh, k_sn, _ptr(zc), _ptr(cam_q), cq[0], cq[1], cq[2],
+                _ptr(cam_k), ck[0], ck[1], ck[2], B, H, N, D, float(out_scale), _variant(variant), _ptr(ws), ws.numel(),
+                _stream(R))
+        rc = lib.te_matmul_relprop_qk_fwd_scaled_f32(_ptr(R), _ptr(r_scale), 0 if r_scale is None else r_scale.stride(0),
+                                                     *tail)
+        if rc == _lib.TE_ERR_UNSUPPORTED and r_scale is not None:
+            R = _c(Deferred(R, r_scale).materialise())     # kernels that take a plain relevance operand
+            rc = lib.te_matmul_relprop_qk_fwd_scaled_f32(_ptr(R), None, 0, *tail)
+        _lib.check(rc, "te_matmul_relprop_qk_fwd_scaled_f32")
     return cam_q, cam_k
 
 
@@ -318,6 +323,14 @@ def add_relprop(R: Tensor, X0: Tensor, X1: Tensor, variant="ours", deferred: boo
             mask = mask.expand(B, N).contiguous()
         out0 = torch.empty_like(X0)
         out1 = torch.empty((B, 1, 1, N), dtype=torch.float32, device=X0.device)
+        if deferred and _variant(variant) == TE_VARIANT_OURS:
+            fac = torch.empty((B, 2), dtype=torch.float32, device=X0.device)
+            with _on_device(X0) as lib, _timed("add_bcast_mask_deferred", 0.0, 4.0 * B * (3 * H * N * N + 2 * N)):
+                ws = _ws(lib.te_add_bcast_relprop_workspace_bytes(B, H, N), X0)
+                _lib.check(lib.te_add_bcast_relprop_deferred_f32(_ptr(R), _ptr(X0), _ptr(mask), _ptr(out0), _ptr(out1),
+                                                                 _ptr(fac), B, H, N, _ptr(ws), ws.numel(), _stream(X0)),
+                           "te_add_bcast_relprop_deferred_f32")
+            return Deferred(out0, fac[:, 0]), out1
         with _on_device(X0) as lib, _timed("add_bcast_mask", 0.0, 4.0 * B * (3 * H * N * N + 2 * N)):
             ws = _ws(lib.te_add_bcast_relprop_workspace_bytes(B, H, N), X0)
             _lib.check(lib.te_add_bcast_relprop_f32(_ptr(R), _ptr(X0), _ptr(mask), _ptr(out0), _ptr(out1), B, H, N,

@@ -140,8 +140,10 @@ class Add(RelProp):
         # deferred=True (model-internal call sites only): the per-sample rescale of layers_ours.py:117-118 travels with
         # the two outputs as an ``ops.Deferred`` and is applied inside the consuming Clone / Linear kernels -- the
         # rule then streams its operands once instead of twice; ``.materialise()`` is bitwise the plain result
-        a, b = ops.add_relprop(R, self.X[0], self.X[1], variant=self.variant,
-                               deferred=deferred and ops.USE_DEFERRED_ADD and self.X[0].shape == self.X[1].shape)
+        x0, x1 = self.X
+        bcast_mask = x0.dim() == 4 and x1.dim() == 4 and x1.shape[1] == 1 and x1.shape[2] == 1       # BERT.py:386-388
+        a, b = ops.add_relprop(R, x0, x1, variant=self.variant,
+                               deferred=deferred and ops.USE_DEFERRED_ADD and (x0.shape == x1.shape or bcast_mask))
         return [a, b]
 
 
