@@ -7,8 +7,9 @@
 127.0.0.1) when it is not already running under a launcher; under one (RANK in the environment, as the driver starts
 it) it asserts WORLD_SIZE == N.  It refuses to run with fewer visible GPUs than ranks.
 
-A "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM: stock PyTorch-ROCm
-forward + attention-gradient backward, then the HIP relprop rules, the gradient x relevance head-mean and the rollout
+A "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM: PyTorch-ROCm forward +
+attention-gradient backward (stock GEMMs / LayerNorm / GELU; the attention blocks themselves on the producer kernels of
+SURVEY.md 8f.1 where the shape qualifies, --producers stock for PyTorch everywhere), then the HIP relprop rules, the gradient x relevance head-mean and the rollout
 chain (LRP.generate_LRP, method "transformer_attribution", start_layer 1 as baselines/ViT/imagenet_seg_eval.py:196 of
 the reference calls it), fp32 end to end.  All blocks are propagated; the only shortcuts are exact or rounding-level
 (DESIGN.md section 3).  Every rank replays its step from a HIP graph captured BEFORE the process group exists (so
@@ -89,8 +90,10 @@ def parse_args(argv=None):
                     help="run the relprop rules on a side stream beside the attention-gradient backward pass")
     ap.add_argument("--inflight", type=int, default=1,
                     help="consecutive steps (batches) in flight, each on its own HIP stream (eager launches)")
-    ap.add_argument("--producers", choices=["stock", "fused"], default="stock",
-                    help="fused: hand-written attention-forward producer kernels where available (SURVEY.md 8f.1)")
+    ap.add_argument("--producers", choices=["stock", "fused"], default="fused",
+                    help="fused (default): the attention blocks' forward and attention-gradient backward run on the "
+                         "hand-written producer kernels where the shape qualifies (SURVEY.md 8f.1: head dim 64, N <= 224 "
+                         "-- ViT-B/16 224^2; ViT-L/384 and BERT-512 stay on stock PyTorch); stock: PyTorch-ROCm everywhere")
     return ap.parse_args(argv)
 
 
@@ -553,20 +556,23 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         idx = CONFIGS[args.config][0]
+        fused_on = args.producers == "fused" and wl.name.startswith("vit") and \
+            ops.attention_forward_supported(wl.tokens, 64)
+        fused_note = "attention blocks on the HIP producer kernels" if fused_on else "stock kernels throughout"
         line = {
             "metric": f"relevance {wl.noun}/sec ({wl.title}, batch {B} per GPU, generate_LRP transformer_attribution)",
             "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{wl.title} batch {B} per GPU on {world}xMI355X: stock fwd + attn-grad bwd + fp32 "
-                                   f"relprop/head-mean/rollout HIP kernels (BASELINE.json configs[{idx}], sharded by "
-                                   f"sample)",
+            "config": {"workload": f"{wl.title} batch {B} per GPU on {world}xMI355X: PyTorch-ROCm fwd + attn-grad bwd "
+                                   f"({fused_note}) + fp32 relprop/head-mean/rollout HIP kernels (BASELINE.json "
+                                   f"configs[{idx}], sharded by sample)",
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": wl.tokens, "blocks": wl.blocks,
                        "start_layer": wl.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "streams": args.streams, "steps_in_flight": args.inflight,
                        "relprop_beside_backward": args.overlap_backward == "on",
                        "blocks_below_start_layer_pruned": args.prune == "on",
-                       "producers": args.producers,
+                       "producers": "fused attention forward/backward kernels" if fused_on else "stock",
                        "stock_gemm_selection": ("PyTorch TunableOp, committed results file" if tuned and
                                                 args.tuned_gemms == "on" else
                                                 "PyTorch TunableOp, tuned in this run" if tuned else "PyTorch default"),
