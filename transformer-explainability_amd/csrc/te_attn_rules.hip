@@ -279,19 +279,21 @@ __device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float
     const int t = wave + s * kWaves;
     if (t < nblk) {
       const int d = (t & 1) * 32 + lr;
+      float x[16];
+      if constexpr (!RAW) {     // all sixteen x values first: a load inside the guard below is a round trip per element
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int j = (t >> 1) * 32 + crow(e, kh);
+          if constexpr (XGLOBAL) x[e] = XG[(int64_t)min(j, nj - 1) * xsn + d];
+          else x[e] = at64(Kt, j, d);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int j = (t >> 1) * 32 + crow(e, kh);
-        if (j < nj) {
-          float val = acc[s][e];
-          if constexpr (!RAW) {
-            float x;
-            if constexpr (XGLOBAL) x = XG[(int64_t)j * xsn + d];
-            else x = at64(Kt, j, d);
-            val = (x * val) * scale;
-          }
-          out[(int64_t)j * osn + d] = val;
-        }
+        float val = acc[s][e];
+        if constexpr (!RAW) val = (x[e] * val) * scale;
+        if (j < nj) out[(int64_t)j * osn + d] = val;
       }
     }
   }
@@ -338,7 +340,6 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   const WideMap wm = wide_map(nj32);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;      // this thread's float4 of the [32][64] S tile
 
-  stage_keys(Vt, v_bh, vs.sn, nj, nj32);
   WideTile ta;
   f32x4 rr = {0.f, 0.f, 0.f, 0.f}, zz = {0.f, 0.f, 0.f, 0.f};
   // part p = 0..5 of tile `it`: the four float4 slots of the attn tile, then the R and Z float4 of the S tile
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   };
 #pragma unroll
   for (int p = 0; p < 6; ++p) fetch_part(0, p);
+  stage_keys(Vt, v_bh, vs.sn, nj, nj32);        // (after the requests of tile 0: one HBM round trip for both)
   f32x16 accv[2];
   zero16(accv[0]);
   zero16(accv[1]);
@@ -449,7 +451,6 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const WideMap wm = wide_map(nj32);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
 
-  stage_keys_T(KtT, k_bh, ks.sn, nj, nj32, JG);
   WideTile tr, tz;
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
   // part p = 0..8 of tile `it`: the four float4 slots of the R tile, of the Z tile, then the q float4
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   };
 #pragma unroll
   for (int p = 0; p < 9; ++p) fetch_part(0, p);
+  stage_keys_T(KtT, k_bh, ks.sn, nj, nj32, JG);      // (after the requests of tile 0: one HBM round trip for both)
   f32x16 acck[2];
   zero16(acck[0]);
   zero16(acck[1]);
@@ -608,8 +610,6 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
   float* o_bh = out + (int64_t)b * N * C + h * 64;
   const int ntiles = (N + TI - 1) / TI;
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
-  stage_keys(Kt, k_bh, sn, nj, nj32);
-  stage_keys_T(VtT, v_bh, sn, nj, nj32, WLD);
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int it) __attribute__((always_inline)) {
     const int i0 = it * TI;
@@ -617,6 +617,8 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
     if (i0 + srow < N) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * sn + (sc << 2));
   };
   fetch(0);
+  stage_keys(Kt, k_bh, sn, nj, nj32);
+  stage_keys_T(VtT, v_bh, sn, nj, nj32, WLD);
   const int ib = wave >> 2, db = wave & 3, l15 = lane & 15, kq = lane >> 4;
   for (int it = 0; it < ntiles; ++it) {
     const int i0 = it * TI;
