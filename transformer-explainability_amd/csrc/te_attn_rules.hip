@@ -300,6 +300,165 @@ __device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// PADDED LDS images of the two rule kernels (the forward producer below keeps the swizzled ones: with k AND v resident it
+// has no room for padding).  [rows][64] tiles have a row stride of SLD = 68 floats, the [TI][keys] tile ALD = 256 (AV:
+// only read 4 bytes per lane along a row) or QLD = 260 (QK: also read as 16-B fragments down 16 rows), the transposed
+// k image [64][QLD].  Every fragment address is then a per-lane base plus a compile-time offset -- no XOR per read, no
+// address registers -- and the column-side products read their K = query-row operands as 4-byte fragments straight
+// from the row-major tiles, so the TRANSPOSED copies of the tile (64 scalar ds_write_b32 + address arithmetic per
+// thread and tile) are gone.  Vector-ALU instructions are not free beside MFMAs: a CU's time for these rules is the
+// SUM of its MFMA cycles and its other vector-instruction cycles.
+// ------------------------------------------------------------------------------------------------
+constexpr int SLD = 68;
+constexpr int ALD = 256;
+constexpr int QLD = 260;
+
+__device__ __forceinline__ void p_store_wide(float* __restrict__ lds, const WideMap& m, const WideTile& t, int ld) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m.row[r] >= 0) *reinterpret_cast<f32x4*>(lds + m.row[r] * ld + (m.c4[r] << 2)) = t.v[r];
+}
+// key-side operand: rows [0, nj) of src [.,64] -> LDS [nj32][SLD], rows >= nj zero
+__device__ __forceinline__ void p_stage_keys(float* __restrict__ Kt, const float* __restrict__ src, int64_t sn, int nj,
+                                             int nj32) {
+  for (int idx = threadIdx.x; idx < nj32 * 16; idx += kT) {
+    const int row = idx >> 4, c = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nj) v = *reinterpret_cast<const f32x4_u*>(src + (int64_t)row * sn + (c << 2));
+    *reinterpret_cast<f32x4*>(Kt + row * SLD + (c << 2)) = v;
+  }
+}
+// ... transposed: element (j, d) -> KtT[d][j], lanes along j (conflict-free scalar LDS stores; the 16-B global loads of
+// a wave touch 64 rows, whose other chunks the same wave fetches in its next trips)
+__device__ __forceinline__ void p_stage_keys_T(float* __restrict__ KtT, const float* __restrict__ src, int64_t sn, int nj,
+                                               int nj32) {
+  const int row = threadIdx.x & 255;
+  if (row < nj32) {
+    for (int c = threadIdx.x >> 8; c < 16; c += 2) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < nj) v = *reinterpret_cast<const f32x4_u*>(src + (int64_t)row * sn + (c << 2));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) KtT[((c << 2) + e) * QLD + row] = v[e];
+    }
+  }
+}
+
+// row-side product, 32x32 output block: acc += A[32 x 64] B[32 x 64]^T.  Ap = A + arow * SLD + 4 kh, Bp likewise: the
+// sixteen 16-B fragments sit at Ap + 8 kg / Bp + 8 kg.  All of them are requested before the first MFMA; `between(kg)`
+// runs after the kg-th group of four MFMAs (see row_product32).
+template <class F>
+__device__ __forceinline__ void p_row_product32(f32x16& acc, bool active, const float* __restrict__ Ap,
+                                                const float* __restrict__ Bp, F&& between) {
+  f32x4 a[8], bq[8];
+  if (active) {
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+      a[kg] = *reinterpret_cast<const f32x4*>(Ap + 8 * kg);
+      bq[kg] = *reinterpret_cast<const f32x4*>(Bp + 8 * kg);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) {
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = TE_MFMA32(a[kg][j], bq[kg][j], acc);
+    }
+    between(kg);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// column-side product of one row tile: acc[s] += W^T[32 keys x 32 rows] Y[32 rows x 32 d] for the 32x32 blocks
+// t = wave + 8 s = 2 jb + db, straight from the ROW-MAJOR tiles: Wp = W + kh * WLD + lr, Yp = Y + kh * SLD + lr; the
+// fragment of query rows (2 m, 2 m + 1) is one 4-byte read at + 2 m * stride.  `between(g)`, g = 0..7, as col_product.
+// Only the first `kgmax` groups of four MFMAs (eight query rows each) run: the rows of the last tile beyond N are zero.
+template <int WLD, class F>
+__device__ __forceinline__ void p_col_product(f32x16 (&acc)[2], const float* __restrict__ Wp, const float* __restrict__ Yp,
+                                              int wave, int nblk, int kgmax, F&& between) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = wave + s * kWaves;
+    const bool active = t < nblk;
+    const float* wp = Wp + (t >> 1) * 32;
+    const float* yp = Yp + (t & 1) * 32;
+    float a[TI / 2], bq[TI / 2];
+    if (active) {
+#pragma unroll
+      for (int m = 0; m < TI / 2; ++m) {
+        a[m] = wp[2 * m * WLD];
+        bq[m] = yp[2 * m * SLD];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kg = 0; kg < TI / 8; ++kg) {
+      if (active && kg < kgmax) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[s] = TE_MFMA32(a[4 * kg + j], bq[4 * kg + j], acc[s]);
+      }
+      between(s * (TI / 8) + kg);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// out = RAW ? acc : (x . acc) * scale for the column accumulators; x from its padded LDS image Kt [keys][SLD] (XLDS) or
+// from global memory -- all sixteen values of a block requested before the first is used
+template <bool RAW, bool XLDS>
+__device__ __forceinline__ void p_col_epilogue(const f32x16 (&acc)[2], const float* __restrict__ Kt,
+                                               const float* __restrict__ XG, int64_t xsn, float* __restrict__ out,
+                                               int64_t osn, int nj, int wave, int lr, int kh, int nblk, float scale) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = wave + s * kWaves;
+    if (t < nblk) {
+      const int d = (t & 1) * 32 + lr;
+      float x[16];
+      if constexpr (!RAW) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int j = (t >> 1) * 32 + crow(e, kh);
+          if constexpr (XLDS) x[e] = Kt[j * SLD + d];
+          else x[e] = XG[(int64_t)min(j, nj - 1) * xsn + d];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int j = (t >> 1) * 32 + crow(e, kh);
+        float val = acc[s][e];
+        if constexpr (!RAW) val = (x[e] * val) * scale;
+        if (j < nj) out[(int64_t)j * osn + d] = val;
+      }
+    }
+  }
+}
+
+// row-side product with a 16x16 output block over the first n16 16-key groups (keys beyond nj are zero in both images):
+// acc += W[16 x keys] X[keys x 16], Wp = W + arow * QLD + 4 kq (the S tile), Xp = k^T + dcol * QLD + 4 kq; two groups per
+// trip (an odd last group alone), the next trip's fragments requested before this trip's eight MFMAs
+__device__ __forceinline__ void p_row_product16(f32x4& acc, const float* __restrict__ Wp, const float* __restrict__ Xp,
+                                                int n16) {
+  const int np = (n16 + 1) >> 1;
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(Wp), a1 = *reinterpret_cast<const f32x4*>(Wp + 16);
+  f32x4 b0 = *reinterpret_cast<const f32x4*>(Xp), b1 = *reinterpret_cast<const f32x4*>(Xp + 16);
+  for (int kp = 0; kp < np; ++kp) {
+    const int o = (kp + 1 < np) ? (kp + 1) * 32 : 0;      // (last trip: a harmless re-read)
+    const f32x4 na0 = *reinterpret_cast<const f32x4*>(Wp + o), na1 = *reinterpret_cast<const f32x4*>(Wp + o + 16);
+    const f32x4 nb0 = *reinterpret_cast<const f32x4*>(Xp + o), nb1 = *reinterpret_cast<const f32x4*>(Xp + o + 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = TE_MFMA16(a0[j], b0[j], acc);
+    if (2 * kp + 1 < n16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = TE_MFMA16(a1[j], b1[j], acc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = na0, a1 = na1, b0 = nb0, b1 = nb1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // AV rule.  R strided [B,H,N,64]; Z contiguous [B*H,N,64]; attn, cam_attn contiguous [B*H,N,N]; v, cam_v strided.
 // grid = BH * ngroups (bh fastest: with BH a multiple of 8 a (b,h)'s groups share an XCD)
 // ------------------------------------------------------------------------------------------------
@@ -323,10 +482,9 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
     int N, int BH, int JG, float scale, long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   long long tprev = prof ? clock64() : 0;
-  float* Vt = smem;                    // [JG][64]   v of this key group (JG = keys per group: 128 / 192 / 256)
-  float* St = Vt + JG * 64;            // [TI][64]   S (row-side A operand, K = d contiguous)
-  float* StT = St + TI * 64;           // [64][TI]   S transposed (column-side B operand, K = query row contiguous)
-  float* WtT = StT + 64 * TI;          // [JG][TI]   the attn tile, transposed (column-side A operand)
+  float* Vt = smem;                    // [JG][SLD]  v of this key group (JG = keys per group: 128 / 192 / 256)
+  float* St = Vt + JG * SLD;           // [TI][SLD]  S: row-side A operand (16-B fragments along d), column-side B operand
+  float* At = St + TI * SLD;           // [TI][ALD]  the attn tile: column-side A operand, and the rule's own factor
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -358,7 +516,7 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   };
 #pragma unroll
   for (int p = 0; p < 6; ++p) fetch_part(0, p);
-  stage_keys(Vt, v_bh, vs.sn, nj, nj32);        // (after the requests of tile 0: one HBM round trip for both)
+  p_stage_keys(Vt, v_bh, vs.sn, nj, nj32);      // (after the requests of tile 0: one HBM round trip for both)
   f32x16 accv[2];
   zero16(accv[0]);
   zero16(accv[1]);
@@ -373,9 +531,8 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);     // rows beyond N: sd(0, 0) = 0
       }
-      *reinterpret_cast<f32x4*>(St + swz64(srow, sc)) = s;
-      store_small_T(StT, srow, sc, s);
-      store_wide_T(WtT, wm, ta);
+      *reinterpret_cast<f32x4*>(St + srow * SLD + (sc << 2)) = s;
+      p_store_wide(At, wm, ta, ALD);
     }
     TE_MARK(2);
     __syncthreads();
@@ -390,11 +547,11 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
       f32x16 gacc;
       zero16(gacc);
       const int jl = wave * 32 + lr;
-      row_product32(gacc, true, St, lr, Vt, jl, kh, [](int) {});
+      p_row_product32(gacc, true, St + lr * SLD + 4 * kh, Vt + jl * SLD + 4 * kh, [](int) {});
       if constexpr (MODE == RULE) {        // the block's sixteen attention values in one LDS round trip
         float av[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) av[e] = atT(WtT, jl, crow(e, kh));
+        for (int e = 0; e < 16; ++e) av[e] = At[crow(e, kh) * ALD + jl];
 #pragma unroll
         for (int e = 0; e < 16; ++e) gacc[e] = (av[e] * gacc[e]) * scale;
       }
@@ -412,11 +569,11 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
       }
     }
     TE_MARK(5);
-    col_product(accv, WtT, StT, wave, lr, kh, 2 * njb, [](int) {});
+    p_col_product<ALD>(accv, At + kh * ALD + lr, St + kh * SLD + lr, wave, 2 * njb, (min(TI, N - i0) + 7) >> 3, [](int) {});
     TE_MARK(6);
   }
   float* o_bh = cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh + (int64_t)j0 * cs.sn;
-  col_epilogue<MODE == BWD, false>(accv, Vt, v_bh, vs.sn, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
+  p_col_epilogue<MODE == BWD, true>(accv, Vt, v_bh, vs.sn, o_bh, cs.sn, nj, wave, lr, kh, 2 * njb, scale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -434,11 +591,11 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     long long* __restrict__ prof, const float* __restrict__ r_scale, int64_t r_scale_stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   long long tprev = prof ? clock64() : 0;
-  float* KtT = smem;                   // [64][JG]   k of this group TRANSPOSED (row-side B operand, K = key contiguous)
-  float* QtT = KtT + JG * 64;          // [64][TI]   q tile transposed (column-side B operand)
-  float* Wt = QtT + 64 * TI;           // [TI][JG]   the S tile (row-side A operand, K = key contiguous)
-  float* WtT = Wt + TI * JG;           // [JG][TI]   the S tile transposed (column-side A operand)
-  float* Pt = WtT + JG * TI;           // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
+  float* KtT = smem;                   // [64][QLD]  k of this group TRANSPOSED (row-side B operand, K = key contiguous)
+  float* Qt = KtT + 64 * QLD;          // [TI][SLD]  q tile (column-side B operand; the rule's own factor of cam_q)
+  float* Wt = Qt + TI * SLD;           // [TI][QLD]  the S tile: row-side A operand (16-B fragments along the keys),
+                                       //            column-side A operand (4-byte fragments down the rows)
+  float* Pt = Wt + TI * QLD;           // BWD only: [TI][64] per-float4 partial dots, then [TI] row dots
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh % H;
   const int j0 = g * JG, nj = min(JG, N - j0), nj32 = (nj + 31) & ~31, njb = nj32 >> 5;
@@ -467,7 +624,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   };
 #pragma unroll
   for (int p = 0; p < 9; ++p) fetch_part(0, p);
-  stage_keys_T(KtT, k_bh, ks.sn, nj, nj32, JG);      // (after the requests of tile 0: one HBM round trip for both)
+  p_stage_keys_T(KtT, k_bh, ks.sn, nj, nj32);        // (after the requests of tile 0: one HBM round trip for both)
   f32x16 acck[2];
   zero16(acck[0]);
   zero16(acck[1]);
@@ -521,15 +678,14 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
           for (int e = 0; e < 4; ++e) tr.v[r][e] = (tz.v[r][e] * (tr.v[r][e] - rd)) * scale;   // zero-filled: 0
         }
     }
-    store_wide(Wt, wm, tr, JG);
-    store_wide_T(WtT, wm, tr);
-    store_small_T(QtT, srow, sc, qq);
+    p_store_wide(Wt, wm, tr, QLD);
+    *reinterpret_cast<f32x4*>(Qt + srow * SLD + (sc << 2)) = qq;
     TE_MARK(2);
     __syncthreads();
     TE_MARK(3);
     // column side first: the nine loads of the next tile go out one per MFMA group (two with the first)
     const bool more = it + 1 < ntiles;
-    col_product(acck, WtT, QtT, wave, lr, kh, 2 * njb, [&](int g) __attribute__((always_inline)) {
+    p_col_product<QLD>(acck, Wt + kh * QLD + lr, Qt + kh * SLD + lr, wave, 2 * njb, (min(TI, N - i0) + 7) >> 3, [&](int g) __attribute__((always_inline)) {
       if (more) {
         fetch_part(it + 1, g);
         if (g == 7) fetch_part(it + 1, 8);
@@ -540,7 +696,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
       // cam_q block (ib, db) = S[16 x keys] k[keys x 16]
       f32x4 cq = {0.f, 0.f, 0.f, 0.f};
       const int arow = ib * 16 + l15, dcol = db * 16 + l15;
-      row_product16(cq, Wt, arow, KtT, dcol, kq, nj32, JG);
+      p_row_product16(cq, Wt + arow * QLD + 4 * kq, KtT + dcol * QLD + 4 * kq, (nj + 15) >> 4);
       TE_MARK(5);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -548,7 +704,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
         if (i0 + il < N) {
           if (ngroups == 1) {
             cam_q[(int64_t)b * cqs.sb + (int64_t)h * cqs.sh + (int64_t)(i0 + il) * cqs.sn + dcol] =
-                (MODE == RULE) ? (atT(QtT, dcol, il) * cq[r]) * scale : cq[r];
+                (MODE == RULE) ? (Qt[il * SLD + dcol] * cq[r]) * scale : cq[r];
           } else {
             qpart[(((int64_t)g * BH + bh) * N + i0 + il) * 64 + dcol] = cq[r];
           }
@@ -558,7 +714,7 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     TE_MARK(6);
   }
   float* o_bh = cam_k + (int64_t)b * cks.sb + (int64_t)h * cks.sh + (int64_t)j0 * cks.sn;
-  col_epilogue<MODE == BWD, true>(acck, KtT, k_bh, ks.sn, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
+  p_col_epilogue<MODE == BWD, false>(acck, nullptr, k_bh, ks.sn, o_bh, cks.sn, nj, wave, lr, kh, 2 * njb, scale);
 }
 
 // cam_q[i,d] = q[i,d] * (sum over groups of qpart[g][bh][i][d], in group order) * scale
@@ -712,9 +868,9 @@ __global__ __launch_bounds__(kT) void attn_fwd_kernel(const float* __restrict__ 
   }
 }
 
-inline size_t lds_av(int jg) { return (size_t)(jg * 64 + 2 * TI * 64 + jg * TI) * sizeof(float); }      // 64 KB at 128 keys
-inline size_t lds_qk(int jg, bool bwd) {                                                              // 72 KB at 128 keys
-  return (size_t)(jg * 64 + TI * 64 + 2 * TI * jg + (bwd ? TI * 64 : 0)) * sizeof(float);
+inline size_t lds_av(int jg) { return (size_t)(jg * SLD + TI * SLD + TI * ALD) * sizeof(float); }      // 109 KB at 256 keys
+inline size_t lds_qk(int /*jg*/, bool bwd) {                                                          // 106 (114) KB
+  return (size_t)(64 * QLD + TI * SLD + TI * QLD + (bwd ? TI * 64 : 0)) * sizeof(float);
 }
 constexpr size_t kLdsFwd = (size_t)(NJF * 64 + 64 * WLD + TI * 64 + TI * WLD) * sizeof(float);   // 160 KB: all of a CU's LDS
 
