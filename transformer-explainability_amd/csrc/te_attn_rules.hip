@@ -37,8 +37,11 @@
 //                            (softmax backward), d_q = d_s k, d_k = d_s^T q
 //
 // All reductions run in a fixed order that depends on N only: a batch equals its samples run one by one, bit for bit.
-// LDS images: [rows][64] tiles with the 16-B chunks of a row XOR-ed by (row & 15) (conflict-free ds_read_b128 over
-// 16 rows, conflict-free ds_read_b32 along a row); the [32][256] tile the same within each group of 16 chunks.
+// LDS images of the rule kernels: PADDED row-major tiles (row strides 68 / 256 / 260 floats, see below) -- every MFMA
+// fragment address is a per-lane base plus a compile-time offset, and both products read the same row-major tile (the
+// row side as 16-B fragments along a row, the column side as 4-byte fragments down the rows).  The forward producer,
+// which holds k AND v, has no room for padding and keeps XOR-swizzled images ([rows][64]: the 16-B chunks of a row
+// XOR-ed by (row & 15); the [32][256] tile the same within each group of 16 chunks).
 #include <stdlib.h>
 #include <string.h>
 
@@ -71,16 +74,6 @@ __device__ __forceinline__ int swzw(int row, int chunk, int ld = WLD) {
 // element (row, x) of a swizzled tile
 __device__ __forceinline__ float at64(const float* __restrict__ T, int row, int x) {
   return T[swz64(row, x >> 2) + (x & 3)];
-}
-__device__ __forceinline__ float atw(const float* __restrict__ T, int row, int x, int ld = WLD) {
-  return T[swzw(row, x >> 2, ld) + (x & 3)];
-}
-// TRANSPOSED images for the column-side products ([x][32 query rows], 128-B rows, K = query row contiguous): chunk
-// XOR-ed by ((x >> 1) ^ (x >> 4)) & 7 -- conflict-free ds_read_b128 over the 16 rows of a lane group (te_linear.hip's
-// scheme), 4-way on the scalar transposing stores (cheaper than the store's own issue time)
-__device__ __forceinline__ int swzT(int x, int chunk) { return x * TI + ((chunk ^ (((x >> 1) ^ (x >> 4)) & 7)) << 2); }
-__device__ __forceinline__ float atT(const float* __restrict__ T, int x, int i) {
-  return T[swzT(x, i >> 2) + (i & 3)];
 }
 __device__ __forceinline__ int crow(int e, int kh) { return (e & 3) + 8 * (e >> 2) + 4 * kh; }
 
@@ -122,15 +115,6 @@ __device__ __forceinline__ WideMap wide_map(int nj32) {
   }
   return m;
 }
-__device__ __forceinline__ void load_wide(WideTile& t, const WideMap& m, const float* __restrict__ src, int64_t ld,
-                                          int rows_valid, int cols_valid) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m.row[r] >= 0 && m.row[r] < rows_valid) v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid);
-    t.v[r] = v;
-  }
-}
 // slot r alone (the QK kernel requests the next tile's slots one at a time between its MFMA groups)
 __device__ __forceinline__ f32x4 load_wide_slot(const WideMap& m, int r, const float* __restrict__ src, int64_t ld,
                                                 int rows_valid, int cols_valid) {
@@ -138,27 +122,6 @@ __device__ __forceinline__ f32x4 load_wide_slot(const WideMap& m, int r, const f
   if (m.row[r] >= 0 && m.row[r] < rows_valid) v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid);
   return v;
 }
-__device__ __forceinline__ void store_wide(float* __restrict__ lds, const WideMap& m, const WideTile& t, int ld) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (m.row[r] >= 0) *reinterpret_cast<f32x4*>(lds + swzw(m.row[r], m.c4[r], ld)) = t.v[r];
-}
-
-// the same tile transposed: element (row i, column x) -> T[x][i]
-__device__ __forceinline__ void store_wide_T(float* __restrict__ lds, const WideMap& m, const WideTile& t) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    if (m.row[r] >= 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) lds[swzT((m.c4[r] << 2) + e, m.row[r] >> 2) + (m.row[r] & 3)] = t.v[r][e];
-    }
-}
-// one float4 (row i, columns 4 c .. 4 c + 3) of a [TI][64] tile, transposed
-__device__ __forceinline__ void store_small_T(float* __restrict__ lds, int i, int c, f32x4 v) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) lds[swzT((c << 2) + e, i >> 2) + (i & 3)] = v[e];
-}
-
 // key-side operand (v or k) of this group: rows [j0, j0 + nj) -> LDS [nj32][64], rows >= nj zero
 __device__ __forceinline__ void stage_keys(float* __restrict__ Kt, const float* __restrict__ src, int64_t sn, int nj,
                                            int nj32) {
@@ -235,70 +198,6 @@ __device__ __forceinline__ void stage_keys_T(float* __restrict__ KtT, const floa
   }
 }
 
-// column-side product of one row tile:  acc[(jb, db)] += W^T[keys x 32] Y[32 x 64] from the TRANSPOSED images
-// WtT [keys][32] and YtT [64][32] (both K-contiguous: one ds_read_b128 feeds four MFMAs), 32x32 blocks t = 2 jb + db,
-// wave w owns t = w and t = w + 8.  `between(g)`, g = 0..7, runs after every group of four MFMAs (whether or not the
-// wave owns a block there): one global memory instruction of the caller per group.
-template <class F>
-__device__ __forceinline__ void col_product(f32x16 (&acc)[2], const float* __restrict__ WtT, const float* __restrict__ YtT,
-                                            int wave, int lr, int kh, int nblk, F&& between) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int t = wave + s * kWaves;
-    const bool active = t < nblk;
-    const int jx = (t >> 1) * 32 + lr, dx = (t & 1) * 32 + lr;
-    f32x4 a[TI / 8], bq[TI / 8];
-    if (active) {
-#pragma unroll
-      for (int kg = 0; kg < TI / 8; ++kg) {
-        a[kg] = *reinterpret_cast<const f32x4*>(WtT + swzT(jx, kg * 2 + kh));
-        bq[kg] = *reinterpret_cast<const f32x4*>(YtT + swzT(dx, kg * 2 + kh));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kg = 0; kg < TI / 8; ++kg) {
-      if (active) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[s] = TE_MFMA32(a[kg][j], bq[kg][j], acc[s]);
-      }
-      between(s * (TI / 8) + kg);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-// RAW: out = acc (backward products), else out = X . acc * scale (relprop rule) with X read from its [keys][64] LDS
-// image (XG == nullptr) or from global memory (XG + j * xsn + d)
-template <bool RAW, bool XGLOBAL>
-__device__ __forceinline__ void col_epilogue(const f32x16 (&acc)[2], const float* __restrict__ Kt,
-                                             const float* __restrict__ XG, int64_t xsn, float* __restrict__ out,
-                                             int64_t osn, int nj, int wave, int lr, int kh, int nblk, float scale) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int t = wave + s * kWaves;
-    if (t < nblk) {
-      const int d = (t & 1) * 32 + lr;
-      float x[16];
-      if constexpr (!RAW) {     // all sixteen x values first: a load inside the guard below is a round trip per element
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int j = (t >> 1) * 32 + crow(e, kh);
-          if constexpr (XGLOBAL) x[e] = XG[(int64_t)min(j, nj - 1) * xsn + d];
-          else x[e] = at64(Kt, j, d);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int j = (t >> 1) * 32 + crow(e, kh);
-        float val = acc[s][e];
-        if constexpr (!RAW) val = (x[e] * val) * scale;
-        if (j < nj) out[(int64_t)j * osn + d] = val;
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // PADDED LDS images of the two rule kernels (the forward producer below keeps the swizzled ones: with k AND v resident it
 // has no room for padding).  [rows][64] tiles have a row stride of SLD = 68 floats, the [TI][keys] tile ALD = 256 (AV:
@@ -371,7 +270,8 @@ __device__ __forceinline__ void p_row_product32(f32x16& acc, bool active, const 
 
 // column-side product of one row tile: acc[s] += W^T[32 keys x 32 rows] Y[32 rows x 32 d] for the 32x32 blocks
 // t = wave + 8 s = 2 jb + db, straight from the ROW-MAJOR tiles: Wp = W + kh * WLD + lr, Yp = Y + kh * SLD + lr; the
-// fragment of query rows (2 m, 2 m + 1) is one 4-byte read at + 2 m * stride.  `between(g)`, g = 0..7, as col_product.
+// fragment of query rows (2 m, 2 m + 1) is one 4-byte read at + 2 m * stride.  `between(g)`, g = 0..7, runs after
+// every group of four MFMAs (whether or not the wave owns a block there): one global memory instruction of the caller.
 // Only the first `kgmax` groups of four MFMAs (eight query rows each) run: the rows of the last tile beyond N are zero.
 template <int WLD, class F>
 __device__ __forceinline__ void p_col_product(f32x16 (&acc)[2], const float* __restrict__ Wp, const float* __restrict__ Yp,
