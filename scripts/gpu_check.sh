@@ -9,7 +9,7 @@ mkdir -p gpurun_out; rm -f gpurun_out/parity_report.jsonl; rm -rf gpurun_out/pro
 ( cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d "$OLDPWD/gpurun_out/prof" -o bench -- \
     python "$OLDPWD/bench.py" --cpu-baseline off > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof_bench.err" )
 rm -f gpurun_out/prof/*agent_info* gpurun_out/prof/*kernel_trace*
-( timeout 300 python bench.py --producers fused --cpu-baseline off > gpurun_out/bench_b64_fused.json 2> gpurun_out/bench_b64_fused.err )
+( timeout 300 python bench.py --producers stock --cpu-baseline off > gpurun_out/bench_b64_stock.json 2> gpurun_out/bench_b64_stock.err )
 for cfg in vit_l16_384 bert_base_512; do
   ( timeout 500 python bench.py --config $cfg --steps 3 --warmup 1 --cpu-maps 2 > gpurun_out/bench_$cfg.json 2> gpurun_out/bench_$cfg.err )
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d "$OLDPWD/gpurun_out/prof_$cfg" -o bench -- \
@@ -19,13 +19,13 @@ done
 ( timeout 200 python scripts/stream_kernels_bw.py 2>&1 | tail -12 ) > gpurun_out/stream_kernels_bw.log
 ( TE_HEADMEAN_VARIANT=0 timeout 100 python scripts/stream_kernels_bw.py --only headmean 2>&1 | tail -3 ) >> gpurun_out/stream_kernels_bw.log
 ( for impl in rules tiles; do echo "TE_ATTN_IMPL=$impl"; for shape in "64 12 197" "32 16 577" "32 12 512"; do
-    TE_ATTN_IMPL=$impl timeout 120 python scripts/attn_bench.py $shape 2>&1 | tail -1; done; done ) > gpurun_out/attn_bench.log
+    TE_ATTN_IMPL=$impl timeout 120 python scripts/attn_bench.py $shape 64 producers 2>&1 | grep -v amdgpu | tail -2; done; done ) > gpurun_out/attn_bench.log
 ( TE_DIST_BACKEND=gloo TE_DEVICE_OVERRIDE=0 timeout 300 python bench.py --gpus 2 --batch 16 --steps 2 --warmup 1 \
     > gpurun_out/bench_2rank_rig.json 2> gpurun_out/bench_2rank_rig.err )
 echo "=== tests ==="; cat gpurun_out/tests_full.log
 echo "=== smoke ==="; cat gpurun_out/smoke.log
 echo "=== bench ==="; cat gpurun_out/bench_b64.json; tail -25 gpurun_out/bench_b64.err
-echo "=== bench, fused producers ==="; cut -c1-330 gpurun_out/bench_b64_fused.json; tail -4 gpurun_out/bench_b64_fused.err
+echo "=== bench, stock producers ==="; cut -c1-330 gpurun_out/bench_b64_stock.json; tail -4 gpurun_out/bench_b64_stock.err
 for cfg in vit_l16_384 bert_base_512; do echo "=== bench $cfg ==="; cut -c1-300 gpurun_out/bench_$cfg.json; tail -3 gpurun_out/bench_$cfg.err; done
 echo "=== rocprof top kernels ==="; head -14 gpurun_out/prof/bench_kernel_stats.csv | cut -d, -f1-4
 echo "=== streaming kernels ==="; cat gpurun_out/stream_kernels_bw.log
