@@ -122,6 +122,54 @@ __device__ __forceinline__ f32x4 load_wide_slot(const WideMap& m, int r, const f
   if (m.row[r] >= 0 && m.row[r] < rows_valid) v = load4(src + (int64_t)m.row[r] * ld, m.c4[r] << 2, cols_valid);
   return v;
 }
+// Branch-free variant for the rule kernels (every key group has nj >= 4 keys: supported()).  The guarded loads above
+// cost ~35 vector / scalar instructions per float4 (64-bit addresses, a divergent branch per slot, a scalar tail) --
+// and a vector instruction beside MFMAs is not free.  Here a slot is ONE 16-B load at uniform
+// base + 32-bit offset: rows beyond N re-read the tile's last row, chunks at / beyond the row's end read its last four
+// columns (always in bounds); fast_fix(), run when the tile is consumed, assembles the partial chunk and zeroes what
+// lies outside.  kind: 0 outside the tile, 1 whole chunk, 2 the row's partial last chunk.
+struct FastMap {
+  int row[4], coff[4], kind[4];
+  int nslots;     // float4 slots of the tile (TI * nj32 / 4): slot round r is wholly outside from r * kT >= nslots on
+  bool fast;      // nj >= 4: the branch-free loads are legal (else the guarded load_wide_slot)
+  bool plain;     // every slot of every thread is a whole in-tile chunk (nj == 256): full tiles need no fast_fix
+};
+__device__ __forceinline__ FastMap fast_map(int nj32, int nj) {
+  FastMap m;
+  const int per_row = nj32 >> 2, tailc = nj >> 2, rem = nj & 3;
+  m.nslots = TI * per_row;
+  m.fast = nj >= 4;
+  m.plain = nj == nj32 && m.nslots == 4 * kT;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int idx = threadIdx.x + r * kT;
+    const int row = idx / per_row, c4 = idx - row * per_row;
+    const bool in = row < TI;
+    m.kind[r] = !in ? 0 : (c4 < tailc ? 1 : ((c4 == tailc && rem != 0) ? 2 : 0));
+    m.row[r] = in ? row : 0;
+    m.coff[r] = (m.kind[r] == 1) ? (c4 << 2) : nj - 4;
+  }
+  return m;
+}
+__device__ __forceinline__ f32x4 fast_load(const FastMap& m, int r, const float* __restrict__ base, int i0, int N,
+                                           int rows_valid) {
+  const unsigned off = (unsigned)(i0 + min(m.row[r], rows_valid - 1)) * (unsigned)N + (unsigned)m.coff[r];
+  return *reinterpret_cast<const f32x4_u*>(base + off);
+}
+__device__ __forceinline__ f32x4 fast_fix(const FastMap& m, int r, f32x4 L, int nj, int rows_valid) {
+  const int rem = nj & 3;
+  f32x4 t;
+  t[0] = rem == 1 ? L[3] : (rem == 2 ? L[2] : L[1]);
+  t[1] = rem == 2 ? L[3] : (rem == 3 ? L[2] : 0.0f);
+  t[2] = rem == 3 ? L[3] : 0.0f;
+  t[3] = 0.0f;
+  const bool ok = m.row[r] < rows_valid, full = ok && m.kind[r] == 1, tail = ok && m.kind[r] == 2;
+  f32x4 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) out[e] = full ? L[e] : (tail ? t[e] : 0.0f);
+  return out;
+}
+
 // key-side operand (v or k) of this group: rows [j0, j0 + nj) -> LDS [nj32][64], rows >= nj zero
 __device__ __forceinline__ void stage_keys(float* __restrict__ Kt, const float* __restrict__ src, int64_t sn, int nj,
                                            int nj32) {
@@ -396,22 +444,23 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   const float* v_bh = v + (int64_t)b * vs.sb + (int64_t)h * vs.sh + (int64_t)j0 * vs.sn;
   const int ntiles = (N + TI - 1) / TI;
   const WideMap wm = wide_map(nj32);
+  const FastMap fm = fast_map(nj32, nj);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;      // this thread's float4 of the [32][64] S tile
 
-  WideTile ta;
+  WideTile ta;                                  // raw (fast_load) until the tile is consumed
   f32x4 rr = {0.f, 0.f, 0.f, 0.f}, zz = {0.f, 0.f, 0.f, 0.f};
   // part p = 0..5 of tile `it`: the four float4 slots of the attn tile, then the R and Z float4 of the S tile
+  // (branch-free: rows beyond N re-read the tile's last row and are zeroed when the tile is consumed)
   auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
     if (p < 4) {
-      ta.v[p] = load_wide_slot(wm, p, a_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      if (!fm.fast) ta.v[p] = load_wide_slot(wm, p, a_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      else if (p * kT < fm.nslots) ta.v[p] = fast_load(fm, p, a_bh, i0, N, rows_valid);
     } else if (p == 4) {
-      rr = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (srow < rows_valid) rr = *reinterpret_cast<const f32x4_u*>(r_bh + (int64_t)(i0 + srow) * rs.sn + (sc << 2));
+      rr = *reinterpret_cast<const f32x4_u*>(r_bh + ((unsigned)(i0 + min(srow, rows_valid - 1)) * (unsigned)rs.sn + (unsigned)(sc << 2)));
     } else if (p == 5) {
-      zz = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (MODE == RULE)
-        if (srow < rows_valid) zz = *reinterpret_cast<const f32x4_u*>(z_bh + (int64_t)(i0 + srow) * zs.sn + (sc << 2));
+        zz = *reinterpret_cast<const f32x4_u*>(z_bh + ((unsigned)(i0 + min(srow, rows_valid - 1)) * (unsigned)zs.sn + (unsigned)(sc << 2)));
     }
   };
 #pragma unroll
@@ -426,12 +475,19 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
     __syncthreads();                       // the previous tile's readers are done (first trip: nothing to wait for)
     TE_MARK(1);
     {
+      const int rows_valid = min(TI, N - i0);
       f32x4 s = rr;                                                  // BWD: the tile of d_out itself
       if constexpr (MODE == RULE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);     // rows beyond N: sd(0, 0) = 0
+        for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = (srow < rows_valid) ? s[e] : 0.0f;      // rows beyond N
       *reinterpret_cast<f32x4*>(St + srow * SLD + (sc << 2)) = s;
+      if (fm.fast && !(fm.plain && rows_valid == TI)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ta.v[r] = fast_fix(fm, r, ta.v[r], nj, rows_valid);
+      }
       p_store_wide(At, wm, ta, ALD);
     }
     TE_MARK(2);
@@ -506,20 +562,23 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const float* k_bh = k + (int64_t)b * ks.sb + (int64_t)h * ks.sh + (int64_t)j0 * ks.sn;
   const int ntiles = (N + TI - 1) / TI;
   const WideMap wm = wide_map(nj32);
+  const FastMap fm = fast_map(nj32, nj);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
 
-  WideTile tr, tz;
+  WideTile tr, tz;                              // raw (fast_load) until the tile is consumed
   f32x4 qq = {0.f, 0.f, 0.f, 0.f};
   // part p = 0..8 of tile `it`: the four float4 slots of the R tile, of the Z tile, then the q float4
+  // (branch-free: rows beyond N re-read the tile's last row and are zeroed when the tile is consumed)
   auto fetch_part = [&](int it, int p) __attribute__((always_inline)) {
     const int i0 = it * TI, rows_valid = min(TI, N - i0);
     if (p < 4) {
-      tr.v[p] = load_wide_slot(wm, p, r_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      if (!fm.fast) tr.v[p] = load_wide_slot(wm, p, r_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      else if (p * kT < fm.nslots) tr.v[p] = fast_load(fm, p, r_bh, i0, N, rows_valid);
     } else if (p < 8) {
-      tz.v[p - 4] = load_wide_slot(wm, p - 4, z_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      if (!fm.fast) tz.v[p - 4] = load_wide_slot(wm, p - 4, z_bh + (int64_t)i0 * N, N, rows_valid, nj);
+      else if ((p - 4) * kT < fm.nslots) tz.v[p - 4] = fast_load(fm, p - 4, z_bh, i0, N, rows_valid);
     } else {
-      qq = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (srow < rows_valid) qq = *reinterpret_cast<const f32x4_u*>(q_bh + (int64_t)(i0 + srow) * qs.sn + (sc << 2));
+      qq = *reinterpret_cast<const f32x4_u*>(q_bh + ((unsigned)(i0 + min(srow, rows_valid - 1)) * (unsigned)qs.sn + (unsigned)(sc << 2)));
     }
   };
 #pragma unroll
@@ -535,6 +594,18 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
     TE_MARK(0);
     __syncthreads();
     TE_MARK(1);
+    {
+      const int rows_valid = min(TI, N - i0);
+      if (fm.fast && !(fm.plain && rows_valid == TI)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          tr.v[r] = fast_fix(fm, r, tr.v[r], nj, rows_valid);
+          tz.v[r] = fast_fix(fm, r, tz.v[r], nj, rows_valid);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qq[e] = (srow < rows_valid) ? qq[e] : 0.0f;
+    }
     if constexpr (MODE == RULE) {
       if (r_scale != nullptr) {            // deferred per-sample factor of the broadcast-mask Add (BERT.py:386-388)
         const float f = r_scale[(int64_t)b * r_scale_stride];
@@ -814,6 +885,7 @@ bool enabled() {
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   int ng, jg;
   groups_for(N, ng, jg);
+  // (32-bit offsets inside a (b, h) view: N <= 4096 and, checked by the launchers, a row stride <= 2^16 floats)
   return D == 64 && N >= 1 && N <= 4096 && B * H * ng <= 0x7fffffff;
 }
 
@@ -824,6 +896,7 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
+  if (r_sn > 65536 || z_sn > 65536) return TE_ERR_UNSUPPORTED;      // 32-bit row offsets inside a (b, h) view
   allow_lds(av_rule_kernel<RULE>, lds_av(256));
   av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), lds_av(jg), stream>>>(
       R, Strided{r_sb, r_sh, r_sn}, Z, Strided{z_sb, z_sh, z_sn}, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v,
@@ -838,6 +911,7 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   int ng, jg;
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
+  if (q_sn > 65536) return TE_ERR_UNSUPPORTED;                       // 32-bit row offsets inside a (b, h) view
   allow_lds(qk_rule_kernel<RULE>, lds_qk(256, false));
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
   qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), lds_qk(jg, false), stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
