@@ -186,6 +186,11 @@ KERNEL_GROUPS = {
     "attention_forward": ("attn_fwd_kernel", "producer: scores + softmax + attn v, ViT_LRP.py:132-152"),
     "attention_backward": ("av_rule_kernel<BWD> + qk_rule_kernel<BWD>", "producer: attention-gradient backward, "
                                                                          "ViT_LRP.py:144-145"),
+    "layernorm_forward": ("ln_fwd_kernel", "producer: LayerNorm forward, layers_ours.py:76 (ViT_LRP.py:184,187,266)"),
+    "layernorm_backward": ("ln_bwd_kernel", "producer: LayerNorm input gradient (+ the bypass gradient of the residual "
+                                            "block), ViT_LRP.py:203-205"),
+    "gelu_forward": ("gelu_fwd_kernel", "producer: GELU forward, layers_ours.py:70 (ViT_LRP.py:57)"),
+    "gelu_backward": ("gelu_bwd_kernel", "producer: GELU input gradient"),
     "add_deferred": ("add_deferred_kernel + add_factors_kernel", "Add.relprop (one pass; rescale applied by the "
                                                                  "consumers), layers_ours.py:97-120"),
     "add": ("add_sums_kernel + add_apply_kernel", "Add.relprop, layers_ours.py:97-120"),

@@ -274,6 +274,24 @@ int te_attention_forward_f32(const float* qkv, float* z_qk, float* attn, float* 
 int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn, float* d_qkv,
                               int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk, te_stream_t stream);
 
+/* The LayerNorm and GELU layers around the Linear rules (modules/layers_ours.py:70-77; ViT_LRP.py:57,184,187,266;
+ * BERT.py:18,52,416,463): their relprop rules are the identity, the path needs their forward values (the X / Y the
+ * neighbouring rules cache) and their input gradient on the way to the attention maps.
+ *   te_layernorm_forward_f32 : x [T,C] -> y = (x - mean) * rstd * weight + bias (bias may be NULL); mean, rstd [T] are
+ *                              kept for the backward.  C a multiple of 4, <= 2048 (te_layernorm_supported).
+ *   te_layernorm_backward_f32: dx = rstd * (a - mean_C(a) - xhat * mean_C(a * xhat)) + add,  a = dy * weight,
+ *                              xhat = (x - mean) * rstd; `add` (NULL = none) is the gradient of the residual branch
+ *                              that bypasses the LayerNorm (ViT_LRP.py:203-205: clone -> norm -> ... -> add).
+ *   te_gelu_forward_f32      : y = 0.5 x (1 + erf(x / sqrt 2)), n a multiple of 4
+ *   te_gelu_backward_f32     : dx = dy (0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi)) */
+int te_layernorm_supported(int64_t C);
+int te_layernorm_forward_f32(const float* x, const float* weight, const float* bias, float* y, float* mean, float* rstd,
+                             int64_t T, int64_t C, float eps, te_stream_t stream);
+int te_layernorm_backward_f32(const float* dy, const float* x, const float* weight, const float* mean, const float* rstd,
+                              const float* add, float* dx, int64_t T, int64_t C, te_stream_t stream);
+int te_gelu_forward_f32(const float* x, float* y, int64_t n, te_stream_t stream);
+int te_gelu_backward_f32(const float* dy, const float* x, float* dx, int64_t n, te_stream_t stream);
+
 /* ---- consumer of a relevance map ---------------------------------------------------
  * replaces baselines/ViT/imagenet_seg_eval.py:214-222 and generate_visualizations.py:99-100 (per map):
  * maps [B,g,g] -> heat [B, g*scale, g*scale] = F.interpolate(scale_factor=scale, mode='bilinear') of each map,

@@ -587,6 +587,33 @@ def test_bert_base_golden_and_oracle(golden_bert_base, golden_bands):
     _assert_within_band("bert_base.golden.nomask", out, g["map_nomask_sl0"], golden_bands, ["bert_base.map_nomask_sl0"])
 
 
+def test_bert_base_with_layer_producers(golden_bert_base, golden_bands):
+    """BERT-base with its LayerNorm / GELU layers on the producer kernels (csrc/te_norm_act.hip; the attention blocks
+    stay stock at this sequence length): logits agree with the stock forward to fp32 rounding, the HIP relprop agrees
+    with the oracle on the tensors the producers cached (tight), the map stays inside the sample's noise band."""
+    from transformer_explainability_amd import ops
+    from transformer_explainability_amd.generators import Generator
+    g = golden_bert_base
+    model = _bert_base(g).to(dev())
+    ids, mask = g["input_ids"].long().to(dev()), g["attention_mask"].to(dev())
+    gen = Generator(model)
+    gen.generate_LRP(input_ids=ids, attention_mask=mask, start_layer=11)
+    stock_logits = model.classifier.Y.detach().clone()
+    ops.USE_FUSED_PRODUCERS = True
+    try:
+        for sl in (0, 11):
+            out = gen.generate_LRP(input_ids=ids, attention_mask=mask, start_layer=sl)
+            check("producer.bert_base.logits", model.classifier.Y.detach(), stock_logits, 1e-5)
+            cache = bert_cache_from_model(model)
+            oh = _one_hot_of(model.classifier.Y.detach().float().cpu())
+            ref = O.bert_relprop(oh, cache, num_heads=12, start_layer=sl)
+            _assert_map(f"producer.bert_base.oracle.map_sl{sl}", out, ref["map"], norm_tol=2e-4, rel_tol=3e-4)
+            _assert_within_band(f"producer.bert_base.golden.map_sl{sl}", out, g[f"map_sl{sl}"], golden_bands,
+                                [f"bert_base.map_sl{sl}"], literal_1e4=(sl == 11))
+    finally:
+        ops.USE_FUSED_PRODUCERS = False
+
+
 # ------------------------------------------------------------------------------------------ full-size configs
 def _fits(bytes_needed):
     free, total = torch.cuda.mem_get_info()

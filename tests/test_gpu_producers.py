@@ -141,3 +141,84 @@ def test_vit_b16_with_fused_producers(fused, golden_bands):
     assert torch.equal(glrp(x2).clone(), lrp.generate_LRP(x2, start_layer=1))
     # pruned path: the lowest block whose gradient is wanted moves up to start_layer
     assert torch.equal(LRP(model, prune=True).generate_LRP(x, start_layer=1), fused_map)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm / GELU producers
+LN_SHAPES = [(2, 197, 768), (3, 50, 1024), (1, 7, 64), (2, 33, 2048), (5, 1, 4), (2, 512, 768)]
+
+
+@pytest.mark.parametrize("B,N,C", LN_SHAPES)
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_layernorm_producer(B, N, C, with_bias):
+    """te_layernorm_forward_f32 / _backward_f32 against torch.nn.functional.layer_norm and its autograd on the same
+    device (fp32 rounding), against fp64 on the host, with and without the bypass gradient, batch = samples bitwise."""
+    from transformer_explainability_amd import ops
+    import torch.nn.functional as F
+    d = dev()
+    x = (rnd((B, N, C), 81) * 3.0 + 0.5).to(d)
+    w = (rnd((C,), 82) * 0.5 + 1.0).to(d)
+    b = rnd((C,), 83).to(d) if with_bias else None
+    dy = rnd((B, N, C), 84).to(d)
+    byp = rnd((B, N, C), 85).to(d)
+    assert ops.layernorm_supported(x)
+    y, mean, rstd = ops.layernorm_forward(x, w, b, 1e-6)
+    xr = x.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), w, b, 1e-6)
+    (dxr,) = torch.autograd.grad(yr, xr, dy)
+    check(f"producer.ln.fwd({B},{N},{C})", y, yr.detach(), 3e-6)
+    dx = ops.layernorm_backward(dy, x, w, mean, rstd)
+    check(f"producer.ln.bwd({B},{N},{C})", dx, dxr, 5e-6)
+    dx2 = ops.layernorm_backward(dy, x, w, mean, rstd, add=byp)
+    assert torch.equal(dx2, byp + dx)                                  # the fused addition is the plain fp32 sum
+    # fp64 on the host: as accurate as the stock kernel
+    x64 = x.double().cpu().requires_grad_(True)
+    y64 = F.layer_norm(x64, (C,), w.double().cpu(), None if b is None else b.double().cpu(), 1e-6)
+    (dx64,) = torch.autograd.grad(y64, x64, dy.double().cpu())
+    e_mine, e_stock = float((y.cpu().double() - y64.detach()).abs().max()), float((yr.detach().cpu().double() - y64.detach()).abs().max())
+    assert e_mine <= 2 * e_stock + 1e-6, (e_mine, e_stock)
+    g_mine, g_stock = float((dx.cpu().double() - dx64).abs().max()), float((dxr.cpu().double() - dx64).abs().max())
+    assert g_mine <= 2 * g_stock + 1e-6, (g_mine, g_stock)
+    one = ops.layernorm_forward(x[:1].contiguous(), w, b, 1e-6)
+    assert torch.equal(one[0], y[:1]) and torch.equal(one[1], mean[:N]) and torch.equal(one[2], rstd[:N])
+    assert torch.equal(ops.layernorm_backward(dy[:1].contiguous(), x[:1].contiguous(), w, one[1], one[2]), dx[:1])
+
+
+@pytest.mark.parametrize("shape", [(2, 197, 3072), (1, 50, 4096), (3, 5, 8), (1, 1, 4)])
+def test_gelu_producer(shape):
+    from transformer_explainability_amd import ops
+    import torch.nn.functional as F
+    d = dev()
+    x = (rnd(shape, 91) * 3.0).to(d)
+    x.view(-1)[:4] = torch.tensor([0.0, -0.0, 30.0, -30.0], device=d)      # zero and the saturated tails
+    dy = rnd(shape, 92).to(d)
+    y = ops.gelu_forward(x)
+    xr = x.clone().requires_grad_(True)
+    yr = F.gelu(xr)
+    (dxr,) = torch.autograd.grad(yr, xr, dy)
+    check(f"producer.gelu.fwd{shape}", y, yr.detach(), 1e-6)
+    dx = ops.gelu_backward(dy, x)
+    check(f"producer.gelu.bwd{shape}", dx, dxr, 2e-6)
+    assert torch.equal(ops.gelu_forward(x[:1].contiguous()), y[:1])
+
+
+def test_residual_layernorm_node(fused):
+    """producers._ResidualLayerNorm (clone -> norm of a pre-norm block as one autograd node) gives the same values and
+    the same input gradient as the two stock nodes."""
+    from transformer_explainability_amd import producers, rules
+    d = dev()
+    norm = rules.LayerNorm(768, eps=1e-6).to(d).eval()
+    with torch.no_grad():
+        norm.weight.copy_(rnd((768,), 95) * 0.5 + 1.0)
+        norm.bias.copy_(rnd((768,), 96))
+    x = (rnd((2, 197, 768), 97) * 2.0).to(d)
+    g1, g2 = rnd((2, 197, 768), 98).to(d), rnd((2, 197, 768), 99).to(d)
+    xa = x.clone().requires_grad_(True)
+    assert producers.norm_usable(xa, norm)
+    x1, n = producers.residual_layer_norm(xa, norm)
+    (dxa,) = torch.autograd.grad([x1, n], xa, [g1, g2])
+    xb = x.clone().requires_grad_(True)
+    nb = torch.nn.functional.layer_norm(xb, (768,), norm.weight, norm.bias, 1e-6)
+    (dxb,) = torch.autograd.grad([xb * 1.0, nb], xb, [g1, g2])
+    assert torch.equal(x1, x)
+    check("producer.residual_ln.fwd", n, nb.detach(), 3e-6)
+    check("producer.residual_ln.bwd", dxa, dxb, 5e-6)

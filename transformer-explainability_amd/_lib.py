@@ -50,6 +50,11 @@ SIGNATURES = {
     "te_attention_forward_supported": (_I, [_I64, _I64]),
     "te_attention_forward_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P]),
     "te_attention_backward_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
+    "te_layernorm_supported": (_I, [_I64]),
+    "te_layernorm_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
+    "te_layernorm_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "te_gelu_forward_f32": (_I, [_P, _P, _I64, _P]),
+    "te_gelu_backward_f32": (_I, [_P, _P, _P, _I64, _P]),
     "te_matmul_relprop_qk_fwd_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
                                           _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_matmul_relprop_qk_fwd_scaled_f32": (_I, [_P, _P, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64,

@@ -302,6 +302,59 @@ def attention_backward(d_out: Tensor, qkv: Tensor, attn: Tensor, num_heads: int,
     return d_attn, d_qkv
 
 
+def layernorm_supported(x: Tensor) -> bool:
+    """The LayerNorm / GELU producer kernels take contiguous fp32 device tensors, rows of <= 2048 elements (multiple of 4)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2
+            and bool(_lib.load().te_layernorm_supported(int(x.shape[-1]))))
+
+
+def layernorm_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor], eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """nn.LayerNorm over the last dimension (modules/layers_ours.py:76): x [..., C] -> (y, mean [T], rstd [T])."""
+    x = _c(x)
+    C = x.shape[-1]
+    T = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty((T,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((T,), dtype=torch.float32, device=x.device)
+    with _on_device(x) as lib, _timed("layernorm_forward", 0.0, 4.0 * 2 * T * C):
+        _lib.check(lib.te_layernorm_forward_f32(_ptr(x), _ptr(_c(weight)), _ptr(_c(bias)) if bias is not None else None,
+                                                _ptr(y), _ptr(mean), _ptr(rstd), T, C, float(eps), _stream(x)),
+                   "te_layernorm_forward_f32")
+    return y, mean, rstd
+
+
+def layernorm_backward(dy: Tensor, x: Tensor, weight: Tensor, mean: Tensor, rstd: Tensor,
+                       add: Optional[Tensor] = None) -> Tensor:
+    """Input gradient of layernorm_forward; `add` (same shape) is summed in -- the gradient of the residual branch that
+    bypasses the LayerNorm (ViT_LRP.py:203-205)."""
+    dy, x = _c(dy), _c(x)
+    C = x.shape[-1]
+    T = x.numel() // C
+    dx = torch.empty_like(x)
+    with _on_device(x) as lib, _timed("layernorm_backward", 0.0, 4.0 * (3 + (add is not None)) * T * C):
+        _lib.check(lib.te_layernorm_backward_f32(_ptr(dy), _ptr(x), _ptr(_c(weight)), _ptr(mean), _ptr(rstd),
+                                                 _ptr(_c(add)) if add is not None else None, _ptr(dx), T, C, _stream(x)),
+                   "te_layernorm_backward_f32")
+    return dx
+
+
+def gelu_forward(x: Tensor) -> Tensor:
+    """nn.GELU (exact erf form; modules/layers_ours.py:70, ViT_LRP.py:57)."""
+    x = _c(x)
+    y = torch.empty_like(x)
+    with _on_device(x) as lib, _timed("gelu_forward", 0.0, 4.0 * 2 * x.numel()):
+        _lib.check(lib.te_gelu_forward_f32(_ptr(x), _ptr(y), x.numel(), _stream(x)), "te_gelu_forward_f32")
+    return y
+
+
+def gelu_backward(dy: Tensor, x: Tensor) -> Tensor:
+    dy, x = _c(dy), _c(x)
+    dx = torch.empty_like(x)
+    with _on_device(x) as lib, _timed("gelu_backward", 0.0, 4.0 * 3 * x.numel()):
+        _lib.check(lib.te_gelu_backward_f32(_ptr(dy), _ptr(x), _ptr(dx), x.numel(), _stream(x)), "te_gelu_backward_f32")
+    return dx
+
+
 # ---------------------------------------------------------------------------------------- a5
 # Model-internal Add rules hand their per-sample rescale to the consuming Clone / Linear kernels (one streaming pass
 # instead of two).  Tests flip this to run the two-pass rule on the same inputs.

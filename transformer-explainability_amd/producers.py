@@ -1,0 +1,83 @@
+"""Host side of the producer kernels of SURVEY.md 8f.1 that are plain layers (LayerNorm, GELU): autograd Functions
+over ``ops.layernorm_* / ops.gelu_*`` (csrc/te_norm_act.hip), used by ``rules.LayerNorm`` / ``rules.GELU`` -- the
+reference's ``modules/layers_ours.py:70-77`` classes -- and by the residual blocks when ``ops.USE_FUSED_PRODUCERS`` is on.
+
+Only the INPUT gradient is produced (the explanation differentiates the logit w.r.t. activations, never w.r.t.
+parameters): the LayerNorm producer is used in eval mode only and leaves ``weight.grad`` / ``bias.grad`` untouched.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def usable(x: torch.Tensor) -> bool:
+    """fp32 device tensor on which the producer kernels apply (rows of <= 2048 elements, a multiple of 4)."""
+    return ops.USE_FUSED_PRODUCERS and torch.is_tensor(x) and ops.layernorm_supported(x)
+
+
+def gelu_usable(x: torch.Tensor) -> bool:
+    return (ops.USE_FUSED_PRODUCERS and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
+            and x.numel() > 0 and x.numel() % 4 == 0)
+
+
+def norm_usable(x: torch.Tensor, norm) -> bool:
+    return (usable(x) and not norm.training and getattr(norm, "weight", None) is not None
+            and tuple(norm.normalized_shape) == (x.shape[-1],))
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y, mean, rstd = ops.layernorm_forward(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        return ops.layernorm_backward(dy, x, weight, mean, rstd), None, None, None
+
+
+class _ResidualLayerNorm(torch.autograd.Function):
+    """``x1, x2 = clone(x); n = norm(x2)`` of a pre-norm residual block (ViT_LRP.py:203-205) as one node: forward returns
+    (x, LayerNorm(x)); backward adds the gradient that arrives on the bypass to the LayerNorm's input gradient INSIDE
+    the backward kernel (autograd would run a separate [T,C] addition for the two uses of x)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y, mean, rstd = ops.layernorm_forward(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, d_bypass, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return d_bypass, None, None, None
+        return ops.layernorm_backward(dy, x, weight, mean, rstd, add=d_bypass), None, None, None
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_forward(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_backward(dy, x)
+
+
+def layer_norm(x, norm):
+    return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+
+
+def residual_layer_norm(x, norm):
+    return _ResidualLayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+
+
+def gelu(x):
+    return _Gelu.apply(x)

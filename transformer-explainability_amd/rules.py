@@ -96,7 +96,11 @@ class ReLU(nn.ReLU, RelProp):
 
 
 class GELU(nn.GELU, RelProp):
-    pass
+    def forward(self, x):
+        from . import producers                      # 8f.1: csrc/te_norm_act.hip behind ops.USE_FUSED_PRODUCERS
+        if getattr(self, "approximate", "none") == "none" and not self.training and producers.gelu_usable(x):
+            return producers.gelu(x)
+        return super().forward(x)
 
 
 class Softmax(nn.Softmax, RelProp):
@@ -104,7 +108,11 @@ class Softmax(nn.Softmax, RelProp):
 
 
 class LayerNorm(nn.LayerNorm, RelProp):
-    pass
+    def forward(self, x):
+        from . import producers
+        if producers.norm_usable(x, self):
+            return producers.layer_norm(x, self)
+        return super().forward(x)
 
 
 class Dropout(nn.Dropout, RelProp):

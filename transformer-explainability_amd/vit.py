@@ -18,7 +18,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, producers
 from . import rules as R_ours
 
 __all__ = ["VisionTransformer", "vit_base_patch16_224", "vit_large_patch16_224", "deit_base_patch16_224",
@@ -215,10 +215,23 @@ def make_vit_module(L):
             self.clone2 = L.Clone()
 
         def forward(self, x):
-            x1, x2 = self.clone1(x, 2)
-            x = self.add1([x1, self.attn(self.norm1(x2))])
-            x1, x2 = self.clone2(x, 2)
-            return self.add2([x1, self.mlp(self.norm2(x2))])
+            x1, n = self._clone_norm(self.clone1, self.norm1, x)
+            x = self.add1([x1, self.attn(n)])
+            x1, n = self._clone_norm(self.clone2, self.norm2, x)
+            return self.add2([x1, self.mlp(n)])
+
+        @staticmethod
+        def _clone_norm(clone, norm, x):
+            """``x1, x2 = clone(x, 2); n = norm(x2)`` (ViT_LRP.py:203-205).  With the producer kernels on, the pair is one
+            autograd node whose backward kernel also adds the bypass gradient (producers._ResidualLayerNorm); the two
+            modules' caches are filled as their forward hooks would."""
+            if producers.norm_usable(x, norm):
+                x1, n = producers.residual_layer_norm(x, norm)
+                clone.X, clone.num = x.detach(), 2
+                norm.X, norm.Y = clone.X, n
+                return x1, n
+            x1, x2 = clone(x, 2)
+            return x1, norm(x2)
 
         def relprop(self, cam, **kwargs):
             """ViT_LRP.py:203-213 (LayerNorm rules are the identity)."""
