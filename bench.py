@@ -477,6 +477,12 @@ def main():
     if args.producers == "fused":
         ops.USE_FUSED_PRODUCERS = True
 
+    if args.streams > 1 and not os.environ.get("TE_ALLOW_STREAMS"):
+        # Known issue (round 2, not understood): LRP(streams=2) on a batch of 64 stops making progress in its second
+        # step on this ROCm build once the two micro-batches' kernels really run side by side (batch 8 runs; the bitwise
+        # streams test of tests/test_gpu_models.py runs at batch 4).  Refuse instead of hanging the box.
+        sys.exit("bench.py: --streams > 1 is disabled (known hang at batch 64, see DESIGN.md section 7); "
+                 "set TE_ALLOW_STREAMS=1 to try it anyway")
     wl = Workload(args, rank, dev)
     B = wl.B
     log(f"rank {rank}/{world}: {wl.title} model + {B} inputs resident on {dev}")

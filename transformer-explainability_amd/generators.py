@@ -58,7 +58,8 @@ class LRP:
     each other's tails (a 12,608-row Linear.relprop pass is 2.3 tile rounds per CU; the third round is a third
     full), and the small streaming kernels of one overlap the MFMA kernels of the other.  Results are identical to
     the single-stream path sample by sample; the per-module caches (``get_attn_cam()`` ...) then hold the LAST
-    micro-batch only."""
+    micro-batch only.  KNOWN ISSUE (round 2): at ViT-B batch 64 on the MI355X, ``streams=2`` stops making progress in
+    its second call (small batches run and are bitwise equal to the serial pass); not diagnosed -- keep the default."""
 
     def __init__(self, model, streams=1, overlap_backward=False, prune=False):
         self.model = model
