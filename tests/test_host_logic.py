@@ -259,6 +259,27 @@ def test_cpu_only_hosts_get_no_silent_fallback():
         ops.clone_relprop((torch.zeros(1, 2, 4), torch.zeros(1, 2, 4)), torch.ones(1, 2, 4))
 
 
+def test_producer_switch_is_inert_off_the_gpu(tiny_vit, golden_vit_tiny):
+    """ops.USE_FUSED_PRODUCERS only selects kernels for fp32 device tensors: on host tensors the LayerNorm / GELU /
+    attention modules must stay on their stock forward (same logits, bit for bit) instead of reaching for the
+    library, and the producer autograd nodes must not appear in the graph."""
+    from transformer_explainability_amd import ops, producers
+    g = golden_vit_tiny
+    stock = tiny_vit(g["x"]).detach().clone()
+    ops.USE_FUSED_PRODUCERS = True
+    try:
+        x = g["x"].clone().requires_grad_(True)
+        out = tiny_vit(x)
+        assert torch.equal(out.detach(), stock)
+        assert not producers.usable(x) and not producers.gelu_usable(x)
+        assert not producers.norm_usable(torch.zeros(2, 5, 64), tiny_vit.blocks[0].norm1)
+        assert all(getattr(b.attn, "_fused_anchor", None) is None for b in tiny_vit.blocks)
+        (gx,) = torch.autograd.grad(out.sum(), x)             # the stock graph differentiates as usual
+        assert torch.isfinite(gx).all()
+    finally:
+        ops.USE_FUSED_PRODUCERS = False
+
+
 def test_bench_refuses_fewer_gpus_than_ranks():
     """`python bench.py --gpus 2` on a host with fewer than 2 GPUs must fail loudly -- never print an n_gpus: 1 line."""
     import os
