@@ -15,18 +15,29 @@ for P in "$P1" "$P2" "$P3" "$P4"; do
       python "$ROOT/scripts/attn_bench.py" 64 12 197 64 producers > "$ROOT/gpurun_out/pmc$i.log" 2>&1 )
 done
 python - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, re
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        if "te_attn" not in k and "rule_kernel" not in k and "attn_fwd" not in k: continue
-        rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open("gpurun_out/attn_pmc_summary.csv", "w") as out:
-    out.write("kernel,counter,mean_per_dispatch,dispatches\n")
-    for k, cs in sorted(rows.items()):
-        for c, v in sorted(cs.items()):
-            out.write(f"{k[-60:]},{c},{sum(v)/len(v):.6g},{len(v)}\n")
-print(open("gpurun_out/attn_pmc_summary.csv").read())
+        m = re.search(r"(av_rule_kernel<\d>|qk_rule_kernel<\d>|attn_fwd_kernel|qk_finish_kernel)", r["Kernel_Name"])
+        if m:
+            rows[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+B, H, N = 64, 12, 197      # scripts/attn_bench.py's shape; <0> = relprop rule, <1> = the backward producer on the same kernel
+nn, nc = 2 * H * N * N, N * H * 64
+alg = {"av_rule_kernel<0>": (nn + 5 * nc) * 4 * B, "qk_rule_kernel<0>": (nn + 4 * nc) * 4 * B,
+       "attn_fwd_kernel": (nn + 4 * nc) * 4 * B, "av_rule_kernel<1>": (nn + 4 * nc) * 4 * B,
+       "qk_rule_kernel<1>": (nn + 4 * nc) * 4 * B}
+out = ["kernel,counter,mean_per_dispatch,dispatches"]
+for k, cs in sorted(rows.items()):
+    for c, v in sorted(cs.items()):
+        out.append(f"{k},{c},{sum(v) / len(v):.6g},{len(v)}")
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        f_kb, w_kb = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+        out.append(f"{k},traffic_bytes(2*FETCH+WRITE KB),{(2 * f_kb + w_kb) * 1024:.6g},")
+        out.append(f"{k},algorithmic_bytes,{alg.get(k, 0):.6g},")
+    if "SQ_INSTS_VALU" in cs and "SQ_INSTS_MFMA" in cs:
+        out.append(f"{k},valu_per_mfma,{sum(cs['SQ_INSTS_VALU']) / sum(cs['SQ_INSTS_MFMA']):.4g},")
+open("gpurun_out/attn_pmc_summary.csv", "w").write("\n".join(out) + "\n")
+print("\n".join(out))
 PY
 tail -3 gpurun_out/pmc1.log

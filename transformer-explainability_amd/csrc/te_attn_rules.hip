@@ -103,9 +103,10 @@ struct WideTile {
 struct WideMap {
   int row[4], c4[4];   // row < 0: no slot
 };
-__device__ __forceinline__ WideMap wide_map(int nj32) {
+// `per_row` float4 slots per tile row: nj32 / 4 packs the tile densely; 64 gives every wave one whole row (the QK rule:
+// with its 260-float row stride a wave that straddles two rows puts 16-B stores of one pass on the same banks)
+__device__ __forceinline__ WideMap wide_map(int per_row) {
   WideMap m;
-  const int per_row = nj32 >> 2;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int idx = threadIdx.x + r * kT;
@@ -134,12 +135,12 @@ struct FastMap {
   bool fast;      // nj >= 4: the branch-free loads are legal (else the guarded load_wide_slot)
   bool plain;     // every slot of every thread is a whole in-tile chunk (nj == 256): full tiles need no fast_fix
 };
-__device__ __forceinline__ FastMap fast_map(int nj32, int nj) {
+__device__ __forceinline__ FastMap fast_map(int per_row, int nj32, int nj) {
   FastMap m;
-  const int per_row = nj32 >> 2, tailc = nj >> 2, rem = nj & 3;
+  const int tailc = nj >> 2, rem = nj & 3;
   m.nslots = TI * per_row;
   m.fast = nj >= 4;
-  m.plain = nj == nj32 && m.nslots == 4 * kT;
+  m.plain = nj == nj32 && nj32 == 256;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int idx = threadIdx.x + r * kT;
@@ -443,8 +444,8 @@ __global__ __launch_bounds__(kT) void av_rule_kernel(
   float* ca_bh = cam_attn + (int64_t)bh * N * N + j0;
   const float* v_bh = v + (int64_t)b * vs.sb + (int64_t)h * vs.sh + (int64_t)j0 * vs.sn;
   const int ntiles = (N + TI - 1) / TI;
-  const WideMap wm = wide_map(nj32);
-  const FastMap fm = fast_map(nj32, nj);
+  const WideMap wm = wide_map(nj32 >> 2);
+  const FastMap fm = fast_map(nj32 >> 2, nj32, nj);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;      // this thread's float4 of the [32][64] S tile
 
   WideTile ta;                                  // raw (fast_load) until the tile is consumed
@@ -561,8 +562,8 @@ __global__ __launch_bounds__(kT) void qk_rule_kernel(
   const float* q_bh = q + (int64_t)b * qs.sb + (int64_t)h * qs.sh;
   const float* k_bh = k + (int64_t)b * ks.sb + (int64_t)h * ks.sh + (int64_t)j0 * ks.sn;
   const int ntiles = (N + TI - 1) / TI;
-  const WideMap wm = wide_map(nj32);
-  const FastMap fm = fast_map(nj32, nj);
+  const WideMap wm = wide_map(64);
+  const FastMap fm = fast_map(64, nj32, nj);
   const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
 
   WideTile tr, tz;                              // raw (fast_load) until the tile is consumed
