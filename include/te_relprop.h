@@ -258,6 +258,17 @@ size_t te_rollout_row0_workspace_bytes(int64_t B, int64_t N);
 int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
                    int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream);
 
+/* OPT-IN variant of te_linear_relprop_fwd_scaled_f32 (same arguments, same rule: modules/layers_ours.py:207-230, variant
+ * ours, alpha = 1, Z from the forward output) whose three products run on bf16 MFMAs at fp32 accuracy: every fp32 operand
+ * is used as the exact sum of three bf16 parts and the six partial products above 2^-24 are accumulated in fp32
+ * (csrc/te_linear_x6.hip; DESIGN.md section 7 for the accuracy and rate measurements).  in_f and out_f multiples of 128;
+ * workspace = the bf16 planes of |X|, |W|, W+^T, W-^T and S. */
+int te_linear_relprop_x6_supported(int64_t T, int64_t in_f, int64_t out_f);
+size_t te_linear_relprop_x6_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f);
+int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_scale_stride, int64_t rows_per_sample,
+                             const float* X, const float* W, const float* Y, const float* bias, float* out,
+                             int64_t T, int64_t in_f, int64_t out_f, void* ws, size_t ws_bytes, te_stream_t stream);
+
 /* ---- producers of the cached tensors ----------------------------------------------------
  * The attention block of baselines/ViT/ViT_LRP.py:132-152 (and its gradient, the tensor save_attn_gradients receives,
  * :144-145) on the fused qkv activation [B,N,3*H*D] ('b n (qkv h d)'), head dim 64, N <= 224 (k and v of a head stay

@@ -587,6 +587,42 @@ def test_bert_base_golden_and_oracle(golden_bert_base, golden_bands):
     _assert_within_band("bert_base.golden.nomask", out, g["map_nomask_sl0"], golden_bands, ["bert_base.map_nomask_sl0"])
 
 
+def test_vit_b16_linear_x6_path(vit_b16, golden_bands):
+    """OPT-IN ops.USE_LINEAR_X6 (Linear rules on bf16 MFMAs, every fp32 operand split into three bf16 parts): the map
+    agrees with the fp32-MFMA path on the same cache far inside the noise band, with the oracle on the same cache to the
+    usual tight bar, a batch equals its samples bitwise, and the class-token shortcut equals the dense evaluation."""
+    from gpu_util import sliced_relprop_state
+    from transformer_explainability_amd import ops
+    from transformer_explainability_amd.generators import LRP
+    model = vit_b16.to(dev())
+    B = 2
+    x = seeded_randn((B, 3, 224, 224), 1).to(dev())
+    lrp = LRP(model)
+    fp32_map = lrp.generate_LRP(x, start_layer=1).clone()
+    oh = _one_hot_of(model.head.Y.detach())
+    ops.USE_LINEAR_X6 = True
+    try:
+        x6_map = model.relprop(oh, method="transformer_attribution", start_layer=1, alpha=1).clone()
+        s = map_stats(x6_map, fp32_map)
+        record("vit_b16.linear_x6.vs_fp32_mfma", **s)
+        assert s["normalised_max_abs"] <= 5e-6 and s["rel_linf"] <= 2e-5, s
+        cache = vit_cache_from_model(model)
+        ref = O.vit_relprop(oh.float().cpu(), cache, num_heads=12, start_layer=1)
+        _assert_map("vit_b16.linear_x6.oracle_same_cache", x6_map, ref["map"], norm_tol=2e-4, rel_tol=3e-4)
+        for i in range(B):
+            with sliced_relprop_state(model, i, B):
+                one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
+                assert torch.equal(one, x6_map[i:i + 1]), i
+        model.exploit_cls_sparsity = False
+        dense = model.relprop(oh, method="transformer_attribution", start_layer=1, alpha=1)
+        model.exploit_cls_sparsity = True
+        assert torch.equal(dense, x6_map), float((dense - x6_map).abs().max())
+    finally:
+        ops.USE_LINEAR_X6 = False
+        model.exploit_cls_sparsity = True
+    model.to("cpu")
+
+
 def test_bert_base_with_layer_producers(golden_bert_base, golden_bands):
     """BERT-base with its LayerNorm / GELU layers on the producer kernels (csrc/te_norm_act.hip; the attention blocks
     stay stock at this sequence length): logits agree with the stock forward to fp32 rounding, the HIP relprop agrees

@@ -155,6 +155,51 @@ def test_linear_from_forward_output(T, in_f, out_f):
     check(f"linear_fwd_nobias({T},{in_f},{out_f})", got_nb, ref, 2e-5)
 
 
+@pytest.mark.parametrize("T,in_f,out_f", [(394, 768, 3072), (140, 256, 384), (130, 3072, 768), (257, 128, 128)])
+def test_linear_x6_split_operand_path(T, in_f, out_f):
+    """OPT-IN path (csrc/te_linear_x6.hip): the rule's three products on bf16 MFMAs with every fp32 operand split into
+    three bf16 parts (six partial products kept).  Must agree with the oracle as closely as the fp32-MFMA path does
+    (same 2e-5 bar), with that path itself, honour the deferred per-sample factor, leave no row dependent on its tile
+    neighbours (bitwise), and fall back to the exact positive-part sum where (Y - b) and |X||W|^T cancel."""
+    from transformer_explainability_amd import ops
+    X, W, R = rnd((T, in_f), 121), rnd((out_f, in_f), 122, 0.05), rnd((T, out_f), 123, 0.01)
+    bias = rnd((out_f,), 124, 0.3)
+    X[0, :3] = 0.0
+    X[1] = 0.0                                                   # an all-zero row: Z = 0 -> S = 0
+    X[2] = X[2].abs() + 0.01
+    W[:5] = -W[:5].abs() - 0.001                                 # row 2 against these: every product negative
+    Xd, Wd, bd, Rd = X.to(dev()), W.to(dev()), bias.to(dev()), R.to(dev())
+    Y = torch.nn.functional.linear(Xd, Wd, bd)
+    fp32 = ops.linear_relprop(Rd, Xd, Wd, alpha=1.0, variant="ours", Y=Y, bias=bd)
+    ops.USE_LINEAR_X6 = True
+    try:
+        assert bool(ops._lib.load().te_linear_relprop_x6_supported(T, in_f, out_f))
+        got = ops.linear_relprop(Rd, Xd, Wd, alpha=1.0, variant="ours", Y=Y, bias=bd)
+        ref = O.linear_relprop(R, X, W, 1.0, "ours")
+        assert torch.isfinite(got).all()
+        check(f"linear_x6({T},{in_f},{out_f})", got, ref, 2e-5)
+        check(f"linear_x6_vs_fp32_mfma({T},{in_f},{out_f})", got, fp32, 2e-5)
+        # fp64: no less accurate than the fp32-MFMA path
+        ref64 = O.linear_relprop(R.double(), X.double(), W.double(), 1.0, "ours")
+        e6, e32 = float((got.cpu().double() - ref64).abs().max()), float((fp32.cpu().double() - ref64).abs().max())
+        record(f"linear_x6_fp64({T},{in_f},{out_f})", x6=e6, fp32_mfma=e32)
+        assert e6 <= 2.0 * e32 + 1e-9 * float(ref64.abs().max()), (e6, e32)
+        # a row's result does not depend on its tile neighbours; a sample-wise factor on R == the scaled R
+        half = ops.linear_relprop(Rd[:T // 2].contiguous(), Xd[:T // 2].contiguous(), Wd, alpha=1.0, variant="ours",
+                                  Y=Y[:T // 2].contiguous(), bias=bd)
+        assert torch.equal(half, got[:T // 2])
+        if T % 2 == 0:
+            fac = torch.tensor([0.75, 1.5], device=dev())
+            scaled = ops.linear_relprop(ops.Deferred(Rd.view(2, T // 2, out_f), fac), Xd.view(2, T // 2, in_f), Wd,
+                                        alpha=1.0, variant="ours", Y=Y.view(2, T // 2, out_f), bias=bd)
+            plain = ops.linear_relprop((Rd.view(2, T // 2, out_f) * fac[:, None, None]).contiguous(),
+                                       Xd.view(2, T // 2, in_f), Wd, alpha=1.0, variant="ours",
+                                       Y=Y.view(2, T // 2, out_f), bias=bd)
+            assert torch.equal(scaled, plain)
+    finally:
+        ops.USE_LINEAR_X6 = False
+
+
 def test_linear_from_forward_output_cancellation():
     """Where (Y - b) and |X||W|^T cancel the kernel must fall back to the plain positive-part sum:
       * rows whose products are ALL negative (X > 0 against W rows < 0): reference Z = 0 exactly -> S = 0;

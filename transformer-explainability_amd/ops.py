@@ -7,6 +7,7 @@ relprop rules; see include/te_relprop.h for the exact semantics and reference ci
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -110,6 +111,12 @@ USE_FORWARD_OUTPUT = True
 USE_FORWARD_PRODUCTS = True
 
 
+# OPT-IN (round 2 study): the three products of the rule on bf16 MFMAs at fp32 accuracy (every fp32
+# operand = the exact sum of three bf16 parts, the six partial products above 2^-24 kept), csrc/te_linear_x6.hip.
+# Default off: TE_LINEAR_X6=1 or ops.USE_LINEAR_X6 = True.
+USE_LINEAR_X6 = os.environ.get("TE_LINEAR_X6", "0") not in ("", "0")
+
+
 def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant="ours",
                    Y: Optional[Tensor] = None, bias: Optional[Tensor] = None) -> Tensor:
     """Linear.relprop: R [..., out], X [..., in], W [out, in] -> [..., in].
@@ -138,6 +145,15 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
         bc = None if bias is None else _c(bias.detach())
         if Yc.shape[0] != T:
             raise _lib.TeError(f"Linear.relprop: Y has {Yc.shape[0]} rows, X has {T}")
+    if (fwd and USE_LINEAR_X6 and Yc.data_ptr() % 16 == 0
+            and _lib.load().te_linear_relprop_x6_supported(T, in_f, out_f)):
+        with _on_device(Xc) as lib:
+            ws = _ws(lib.te_linear_relprop_x6_workspace_bytes(T, in_f, out_f), Xc)
+            with _timed("linear_x6", 2.0 * T * (3 * in_f) * out_f, 4.0 * (3 * T * in_f + 2 * T * out_f) + 6.0 * 2 * T * out_f):
+                _lib.check(lib.te_linear_relprop_x6_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc), _ptr(Yc),
+                                                        _ptr(bc), _ptr(out), T, in_f, out_f, _ptr(ws), ws.numel(),
+                                                        _stream(Xc)), "te_linear_relprop_x6_f32")
+        return out.reshape(*lead, in_f)
     if KERNEL_TIMER is not None and fast_ok:
         # bench.py roofline probe: same two kernels, launched one by one so that each launch can be
         # bracketed by HIP events on the stream it runs on
