@@ -258,16 +258,44 @@ size_t te_rollout_row0_workspace_bytes(int64_t B, int64_t N);
 int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B, int64_t N,
                    int flags, float* joint, void* ws, size_t ws_bytes, te_stream_t stream);
 
-/* OPT-IN variant of te_linear_relprop_fwd_scaled_f32 (same arguments, same rule: modules/layers_ours.py:207-230, variant
- * ours, alpha = 1, Z from the forward output) whose three products run on bf16 MFMAs at fp32 accuracy: every fp32 operand
- * is used as the exact sum of three bf16 parts and the six partial products above 2^-24 are accumulated in fp32
- * (csrc/te_linear_x6.hip; DESIGN.md section 7 for the accuracy and rate measurements).  in_f and out_f multiples of 128;
- * workspace = the bf16 planes of |X|, |W|, W+^T, W-^T and S. */
+/* te_linear_relprop_fwd_scaled_f32 (same rule: modules/layers_ours.py:207-230, variant ours, alpha = 1, Z from the
+ * forward output, optional per-sample factor on R) with its three products on bf16 MFMAs at fp32 accuracy: every fp32
+ * operand is used as the exact sum of three bf16 parts and the six partial products above 2^-24 are accumulated in fp32
+ * (csrc/te_linear_x6.hip).  in_f, out_f >= 128, out_f % 128 == 0, in_f % 64 == 0.
+ *
+ * Operand planes ("P3"): an fp32 [rows, K] operand as bf16 planes in MFMA-fragment order
+ * [ceil(rows / 32)][K / 16][3 planes][k-half 2][row 32][8 bf16]; te_linear_x6_planes_bytes gives the size.
+ *   te_linear_x6_prepare_weights_f32   W [out_f, in_f] -> the weight-side planes of both passes (|W| as P3, then
+ *                                      max(W,0)^T / min(W,0)^T interleaved per 32-row block); a caller evaluates this
+ *                                      ONCE per weight version and passes the result as w_planes
+ *   te_linear_x6_split_abs_f32         X [rows, K] -> P3 planes of |X| (what a producer of X may emit itself)
+ *   te_linear_relprop_x6_f32           x_planes = NULL: |X| is split into the workspace first.
+ * Workspace = |X| planes, S planes (the Z-pass writes S only in plane form), 64 MiB of accumulator hand-over between
+ * workgroups that share a tile (sequential stream-K: one k-ordered chain per output wherever a tile is cut), flags.
+ * flags: TE_X6_TILE_AUTO (256 weight rows per tile, one 512-thread workgroup per CU, where the shape allows; the result
+ * does not depend on the tile geometry, bit for bit), TE_X6_TILE_128 (128 weight rows, two 256-thread workgroups per CU).
+ * te_linear_relprop_x6_check (synchronises) returns 1 if a bounded hand-over wait of the last call expired. */
+#define TE_X6_TILE_AUTO 0
+#define TE_X6_TILE_128 1
+/* optional phase mask (measurement: one phase per call on the same workspace, in this order); 0 = the whole rule */
+#define TE_X6_PHASE_SPLIT 4    /* clear the flags, |X| -> planes (unless x_planes is given) */
+#define TE_X6_PHASE_Z 8        /* S planes */
+#define TE_X6_PHASE_C 16       /* out */
+#define TE_X6_PHASE_MASK 28
 int te_linear_relprop_x6_supported(int64_t T, int64_t in_f, int64_t out_f);
 size_t te_linear_relprop_x6_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f);
+size_t te_linear_x6_weight_planes_bytes(int64_t in_f, int64_t out_f);
+size_t te_linear_x6_planes_bytes(int64_t rows, int64_t K);
+int te_linear_x6_prepare_weights_f32(const float* W, int64_t in_f, int64_t out_f, void* planes, size_t planes_bytes,
+                                     te_stream_t stream);
+int te_linear_x6_split_abs_f32(const float* X, int64_t rows, int64_t K, void* planes, size_t planes_bytes,
+                               te_stream_t stream);
 int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_scale_stride, int64_t rows_per_sample,
-                             const float* X, const float* W, const float* Y, const float* bias, float* out,
-                             int64_t T, int64_t in_f, int64_t out_f, void* ws, size_t ws_bytes, te_stream_t stream);
+                             const float* X, const float* W, const void* w_planes, const void* x_planes,
+                             const float* Y, const float* bias, float* out,
+                             int64_t T, int64_t in_f, int64_t out_f, int flags, void* ws, size_t ws_bytes,
+                             te_stream_t stream);
+int te_linear_relprop_x6_check(const void* ws, int64_t T, int64_t in_f, int64_t out_f, te_stream_t stream);
 
 /* ---- producers of the cached tensors ----------------------------------------------------
  * The attention block of baselines/ViT/ViT_LRP.py:132-152 (and its gradient, the tensor save_attn_gradients receives,

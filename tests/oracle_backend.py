@@ -16,7 +16,7 @@ def _plain(r):
     return r.materialise() if isinstance(r, ops.Deferred) else r
 
 
-def linear_relprop(R, X, W, alpha=1.0, variant="ours", Y=None, bias=None):
+def linear_relprop(R, X, W, alpha=1.0, variant="ours", Y=None, bias=None, cache=None):
     return O.linear_relprop(_plain(R), X, W, alpha=alpha, variant=variant)     # Y / bias: a device-side shortcut only
 
 

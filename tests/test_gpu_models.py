@@ -588,9 +588,10 @@ def test_bert_base_golden_and_oracle(golden_bert_base, golden_bands):
 
 
 def test_vit_b16_linear_x6_path(vit_b16, golden_bands):
-    """OPT-IN ops.USE_LINEAR_X6 (Linear rules on bf16 MFMAs, every fp32 operand split into three bf16 parts): the map
-    agrees with the fp32-MFMA path on the same cache far inside the noise band, with the oracle on the same cache to the
-    usual tight bar, a batch equals its samples bitwise, and the class-token shortcut equals the dense evaluation."""
+    """ops.USE_LINEAR_X6 (DEFAULT since round 3: Linear rules on bf16 MFMAs, every fp32 operand split into three bf16
+    parts) against the fp32-MFMA kernels: the maps agree on the same cache far inside the noise band, the x6 map agrees
+    with the oracle on the same cache to the usual tight bar, a batch equals its samples bitwise, and the class-token
+    shortcut equals the dense evaluation."""
     from gpu_util import sliced_relprop_state
     from transformer_explainability_amd import ops
     from transformer_explainability_amd.generators import LRP
@@ -598,10 +599,13 @@ def test_vit_b16_linear_x6_path(vit_b16, golden_bands):
     B = 2
     x = seeded_randn((B, 3, 224, 224), 1).to(dev())
     lrp = LRP(model)
-    fp32_map = lrp.generate_LRP(x, start_layer=1).clone()
-    oh = _one_hot_of(model.head.Y.detach())
-    ops.USE_LINEAR_X6 = True
+    was = ops.USE_LINEAR_X6
+    ops.USE_LINEAR_X6 = False
     try:
+        fp32_map = lrp.generate_LRP(x, start_layer=1).clone()
+        oh = _one_hot_of(model.head.Y.detach())
+        ops.USE_LINEAR_X6 = True
+        ops.X6_CHECK = True
         x6_map = model.relprop(oh, method="transformer_attribution", start_layer=1, alpha=1).clone()
         s = map_stats(x6_map, fp32_map)
         record("vit_b16.linear_x6.vs_fp32_mfma", **s)
@@ -618,7 +622,8 @@ def test_vit_b16_linear_x6_path(vit_b16, golden_bands):
         model.exploit_cls_sparsity = True
         assert torch.equal(dense, x6_map), float((dense - x6_map).abs().max())
     finally:
-        ops.USE_LINEAR_X6 = False
+        ops.USE_LINEAR_X6 = was
+        ops.X6_CHECK = False
         model.exploit_cls_sparsity = True
     model.to("cpu")
 

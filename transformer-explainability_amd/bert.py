@@ -132,7 +132,7 @@ def make_bert_module(L):
             rk, rv = torch.empty_like(rq), torch.empty_like(rq)
             as_heads = lambda t: t.view(B, N, H, D).permute(0, 2, 1, 3)          # noqa: E731  (views)
             cam1, _ = ops.matmul_relprop_av(as_heads(cam), probs, v, out_scale=0.5, cam_v_out=as_heads(rv), variant=var,
-                                            z=getattr(self.matmul2, "Y", None))
+                                            z=R_ours._cached_y(self.matmul2))
             self.save_attn_cam(cam1)
             if getattr(self, "_stop_after_attn_cam", False):   # Generator(prune=True): nothing below is read
                 raise L.StopRelprop()
@@ -140,7 +140,7 @@ def make_bert_module(L):
                 # (deferred: the Add's per-sample rescale rides with cam1 into the QK rule's S tile)
                 cam1, _ = self.add.relprop(cam1, deferred=True, **kwargs)           # BERT.py:386-388
             ops.matmul_relprop_qk(cam1, q, kt.transpose(-1, -2), out_scale=0.5, cam_q_out=as_heads(rq),
-                                  cam_k_out=as_heads(rk), variant=var, z=getattr(self.matmul1, "Y", None))
+                                  cam_k_out=as_heads(rk), variant=var, z=R_ours._cached_y(self.matmul1))
             rq = self.query.relprop(rq, **kwargs)
             rk = self.key.relprop(rk, **kwargs)
             rv = self.value.relprop(rv, **kwargs)
@@ -235,8 +235,10 @@ def make_bert_module(L):
             alpha = kwargs.get("alpha", 1)
             var = self.clone.variant
             cls = lambda t: t[:, :1]                                             # noqa: E731
-            lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,     # noqa: E731
-                                                  Y=cls(m.Y), bias=m.bias)
+            def lin(r, m):       # the staleness guard of the cached forward output applies here as in Linear.relprop
+                y = R_ours._cached_y(m)
+                return ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,
+                                          Y=None if y is None else cls(y), bias=m.bias, cache=R_ours.x6_cache(m))
             dfr = ops.USE_DEFERRED_ADD
             c1, c2 = ops.add_relprop(cam_cls, cls(self.output.add.X[0]), cls(self.output.add.X[1]), variant=var,
                                      deferred=dfr)

@@ -1,49 +1,66 @@
 // te_linear_x6.hip -- Linear.relprop (modules/layers_ours.py:207-230, variant "ours", alpha = 1, Z from the cached
-// forward output) with its three GEMM-shaped products on bf16 MFMAs at fp32 accuracy.  OPT-IN this round
-// (ops.USE_LINEAR_X6 / TE_LINEAR_X6=1): the default path is the fp32-MFMA kernels of te_linear.hip.
+// forward output) with its three GEMM-shaped products on bf16 MFMAs at fp32 accuracy.
 //
 // An fp32 number is exactly the sum of three bf16 numbers, a = a0 + a1 + a2 (8 + 8 + 8 significand bits), and a product
 // of two bf16 values is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Of the nine partial products of
-// a b the six above 2^-24 |a||b| are kept:
+// a b the six above 2^-24 |a||b| are kept, smallest first:
 //        a b  ~=  a1 b1 + a0 b2 + a2 b0 + a0 b1 + a1 b0 + a0 b0          ("x6": what is dropped is below fp32 rounding)
-// Measured: error against fp64 BELOW the fp32 GEMM's own (the products are exact, only the
-// accumulation rounds), the ViT-B map moves less than under a K-permutation of the fp32 rule; six bf16 MFMAs sustain
-// 2.15x the rate of one fp32 MFMA on this chip.
+// so every product of the rule is an fp32-accumulated sum of exact terms -- at least as accurate against fp64 as the
+// fp32-MFMA kernels of te_linear.hip (tests/test_gpu_rules.py::test_linear_x6_*).
 //
-//   split kernels   fp32 [R,K] -> bf16 planes, per row and per 32-k block [3][32] (the 192-B tile row of one K-step is
-//                   contiguous in memory and in LDS); op = |x| (Z-pass operands), or max(w,0) / min(w,0) of W^T (the
-//                   C-pass's K = out_f operands)
-//   zpass_x6        A = |X| |W|^T ; Z = ((Y - b) + A) / 2 (cancellation guard as te_linear.hip) ; S = sd(R f, Z), written
-//                   directly as bf16 planes -- the C-pass's A operand never exists in fp32
-//   cpass_x6        P+ = S W+, P- = S W- (one pass over S, two accumulator sets) ; out = X+ . P+ + X- . P-
-//
-// Tiles 128 x 128 (Z-pass) / 128 x 64 (C-pass, two products), 256 threads as 2 x 2 waves, K-step 32 = two K16 slices;
-// global -> registers -> LDS staging with the next K-step's loads in flight during the MFMAs; LDS rows padded to 208 B
-// (16-B fragments of a lane group land on distinct bank groups).  Row t of every output depends on row t of the inputs
-// only and its MFMA chain is k-ordered: a batch equals its samples run one by one, bit for bit.
-// Shapes: in_f and out_f multiples of 128 (every Linear of ViT-B/L and BERT-base except the classifier head).
+// Round 3 design:
+//   plane tensors   an fp32 [R, K] operand lives as bf16 planes in FRAGMENT-MAJOR order
+//                        P3[R / 32][K / 16][3 planes][kh 2][r 32][8 bf16]          (1 KiB per plane fragment)
+//                   i.e. exactly the image one wave needs as an MFMA operand of a 32-row block and one K16 step: one
+//                   global_load_lds_dwordx4 (64 lanes x 16 B, fully coalesced 1 KiB) stages it, one ds_read_b128 per
+//                   lane reads it back conflict-free.  The C-pass weights interleave W+^T and W-^T per block:
+//                        P6[in / 32][out / 16][sign 2][3 planes][1 KiB].
+//   weights         split ONCE per weight version (te_linear_x6_prepare_weights_f32; the host caches the planes)
+//   |X| planes      te_linear_x6_split_abs_f32 (one streaming pass)
+//   one GEMM kernel x6_kernel<WM, MODE>: the product is evaluated TRANSPOSED, D[w][t] (weight rows x activation rows),
+//                   so a lane of the 32x32 accumulator block owns ONE activation row t and runs of four consecutive
+//                   features: R / Y / X are read and the fp32 result is stored as 16-byte pieces, and the Z-pass writes
+//                   S straight into the plane layout of the C-pass's operand (halves exchanged with
+//                   v_permlane32_swap) -- S never exists in fp32.
+//                   Tile = (128 WM) weight rows x 256 activation rows, 4 WM waves of 128 x 64 (eight 32x32 blocks, 48
+//                   MFMAs per K16 step), two LDS stages filled by direct-to-LDS loads one step ahead, one barrier per
+//                   step.  C-pass: the "weight rows" of a wave are (32 i) x {+, -} pairs, P+ and P- side by side.
+//   schedule        persistent grid, SEQUENTIAL stream-K: the (tile, K-step) iteration space is cut into equal
+//                   contiguous ranges, one per workgroup.  A tile cut in two is computed as ONE k-ordered chain: the
+//                   workgroup holding its head (k = 0 ...) runs that fragment FIRST and publishes the accumulators
+//                   (agent-scope release), the workgroup holding its tail runs it LAST, starting from those accumulators
+//                   (agent-scope acquire).  Every output therefore sees the same fused-multiply-add chain wherever the cut
+//                   falls: a batch equals its samples run one by one, bit for bit, and no tile quantisation is left (at
+//                   ViT-B batch 64 the 256-wide tiles of the eight launches of a block fill 59-94 % of whole rounds).
+//                   Waits only ever go to a LOWER workgroup index of the same XCD slot order.
+#include <algorithm>
+
 #include "te_common.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BK = 32;
-constexpr int kThreads = 256;
-constexpr int ROWB = 192;            // bytes of one row of one K-step in memory: 3 planes x 32 bf16
-constexpr int LROW = 208;            // ... in LDS: 52 dwords per row -> the 16-B fragments of 16 rows cover all 64 banks
+constexpr int kFrag = 1024;                   // one plane fragment: 32 rows x 16 k bf16 as [kh][r][8]
+constexpr int kRB = 3 * kFrag;                // one 32-row block, one K16 step
+constexpr int kTileT = 256;                   // activation rows per tile (4 wave columns x 64)
+constexpr int kMinFrag = 4;                   // a cut closer than this many K-steps to a tile boundary snaps onto it
 constexpr float kCancelTol = 0.0078125f;      // as te_linear.hip
+constexpr unsigned kSpinLimit = 1u << 22;     // bounded wait for a predecessor's accumulators (~1 s): never hang the GPU
+
+enum { MODE_Z = 0, MODE_C = 1 };
 
 #define TE_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ unsigned short bf16_rn(float x) {      // round to nearest even, finite input
+__device__ __forceinline__ unsigned bf16_rn(float x) {      // round to nearest even, finite input
   const unsigned u = __float_as_uint(x);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ float bf16_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ float bf16_f32(unsigned b) { return __uint_as_float(b << 16); }
 // x = p[0] + p[1] + p[2] exactly (the residual of a round-to-nearest bf16 is representable in fp32)
-__device__ __forceinline__ void split3(float x, unsigned short (&p)[3]) {
+__device__ __forceinline__ void split3(float x, unsigned (&p)[3]) {
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     p[q] = bf16_rn(x);
@@ -60,49 +77,56 @@ __device__ __forceinline__ float apply_op(float x) {
   return __int_as_float(b < 0 ? b : 0);
 }
 
-// dst row layout: [K / 32 blocks][3 planes][32 k].  One thread = 8 consecutive k of one row.
-// TRANSPOSE: the source is [K][R] (row r of the result is column r of the source): the weight operands of the C-pass.
+// ------------------------------------------------------------------------------------------------
+// fp32 -> planes.  One 256-thread block = 32 rows x 8 K16 steps; thread (r = t & 31, step = t >> 5) reads 16
+// consecutive k of its row and writes the six 16-B pieces (3 planes x 2 k-halves) of its (row, step): a half-wave
+// writes 512 contiguous bytes per store.  TRANSPOSE: element (r, k) is src[k * R + r] (W^T operands of the C-pass);
+// the destination then is the P6 layout with `sign` selecting the W+ / W- half.
+// ------------------------------------------------------------------------------------------------
 template <int OP, bool TRANSPOSE>
-__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                    int64_t R, int64_t K) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t per_row = K >> 3;
-  if (idx >= R * per_row) return;
-  int64_t row;
-  int c8;
-  float v[8];
-  if constexpr (!TRANSPOSE) {
-    row = idx / per_row;
-    c8 = (int)(idx - row * per_row);
-    const float* s = src + row * K + (int64_t)c8 * 8;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(s), v1 = *reinterpret_cast<const f32x4*>(s + 4);
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                                    int64_t R, int64_t K, int group, int sign) {
+  const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t rb = blockIdx.x;
+  const int64_t ks = (int64_t)blockIdx.y * 8 + sl;
+  const int64_t nks = K >> 4;
+  if (ks >= nks) return;
+  const int64_t row = rb * 32 + r;
+  float v[16];
+  if (row < R) {
+    if constexpr (!TRANSPOSE) {
+      const float* s = src + row * K + ks * 16;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = v0[e];
-      v[4 + e] = v1[e];
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(s + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * c + e] = q[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = src[(ks * 16 + e) * R + row];
     }
   } else {
-    // consecutive threads take consecutive rows r (coalesced reads along a source row)
-    c8 = (int)(idx / R);
-    row = idx - (int64_t)c8 * R;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = src[((int64_t)c8 * 8 + e) * R + row];
+    for (int e = 0; e < 16; ++e) v[e] = 0.0f;
   }
-  unsigned short p[8][3];
+  unsigned p[16][3];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split3(apply_op<OP>(v[e]), p[e]);
-  unsigned short* d = dst + row * (K / 32) * 96 + (int64_t)(c8 >> 2) * 96 + (c8 & 3) * 8;
+  for (int e = 0; e < 16; ++e) split3(apply_op<OP>(v[e]), p[e]);
+  unsigned char* d = dst + ((rb * nks + ks) * group + sign * 3) * kFrag + r * 16;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    u32x4 w;
+  for (int q = 0; q < 3; ++q)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = (unsigned)p[2 * e][q] | ((unsigned)p[2 * e + 1][q] << 16);
-    *reinterpret_cast<u32x4*>(d + q * 32) = w;
-  }
+    for (int kh = 0; kh < 2; ++kh) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = p[8 * kh + 2 * e][q] | (p[8 * kh + 2 * e + 1][q] << 16);
+      *reinterpret_cast<u32x4*>(d + q * kFrag + kh * 512) = w;
+    }
 }
 
 // plain positive-part sum of one output element (the reference's Z), k-ordered: the cancellation fallback
-__device__ __noinline__ float exact_z(const float* __restrict__ x, const float* __restrict__ w, int64_t K) {
+__device__ __forceinline__ float exact_z(const float* __restrict__ x, const float* __restrict__ w, int64_t K) {
   float z1 = 0.0f, z2 = 0.0f;
   for (int64_t k = 0; k < K; ++k) {
     const float xv = x[k], wv = w[k];
@@ -112,272 +136,522 @@ __device__ __noinline__ float exact_z(const float* __restrict__ x, const float* 
   return z1 + z2;
 }
 
-// six partial products of one K16 slice, smallest first
-__device__ __forceinline__ f32x16 mma_x6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
-  c = TE_MFMA_BF16(a[1], b[1], c);
-  c = TE_MFMA_BF16(a[0], b[2], c);
-  c = TE_MFMA_BF16(a[2], b[0], c);
-  c = TE_MFMA_BF16(a[0], b[1], c);
-  c = TE_MFMA_BF16(a[1], b[0], c);
-  c = TE_MFMA_BF16(a[0], b[0], c);
-  return c;
-}
-
-// rows [row0, row0 + ROWS) of a split operand, K-step kt -> registers (rows past `rows` re-read the last row: their
-// products are never stored) ; registers -> LDS [ROWS][LROW]
-template <int ROWS>
-__device__ __forceinline__ void load_planes(u32x4 (&reg)[ROWS * 12 / kThreads], const unsigned short* __restrict__ Ps,
-                                            int64_t rows, int64_t rowbytes, int64_t row0, int kt) {
-#pragma unroll
-  for (int i = 0; i < ROWS * 12 / kThreads; ++i) {
-    const int idx = threadIdx.x + i * kThreads;
-    const int row = idx / 12, c = idx - row * 12;
-    const int64_t gr = min(row0 + row, rows - 1);
-    reg[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(Ps) + gr * rowbytes + (int64_t)kt * ROWB + c * 16);
-  }
-}
-template <int ROWS>
-__device__ __forceinline__ void store_planes(unsigned char* __restrict__ lds, const u32x4 (&reg)[ROWS * 12 / kThreads]) {
-#pragma unroll
-  for (int i = 0; i < ROWS * 12 / kThreads; ++i) {
-    const int idx = threadIdx.x + i * kThreads;
-    const int row = idx / 12, c = idx - row * 12;
-    *reinterpret_cast<u32x4*>(lds + row * LROW + c * 16) = reg[i];
-  }
-}
-
-struct RowScale {
-  const float* s;
-  int64_t stride;
+struct X6Params {
+  const unsigned char* A;      // weight-side planes: P3 of |W| (Z-pass) or P6 of W+^T / W-^T (C-pass)
+  const unsigned char* B;      // activation-side planes (P3): |X| (Z-pass) or S (C-pass)
+  int64_t a_group_stride;      // bytes between consecutive 32-row groups of A  = nks * (3 or 6) KiB
+  int64_t b_rb_stride;         // bytes between consecutive 32-row blocks of B  = nks * 3 KiB
+  int nks;                     // K / 16
+  int ntm, ntn;                // tiles along the weight side / the activation side
+  int ncb;                     // 32-row blocks of the activation side = ceil(T / 32)
+  int64_t T;
+  int in_f, out_f;
+  float* partial;              // [grid][threads][32] float4: accumulators of a cut tile
+  unsigned* flags;             // [grid], zero before the launch; [grid] = error word
+  // Z-pass epilogue
+  const float* R;
+  const float* Y;
+  const float* bias;
+  const float* X;              // fp32 operands: the cancellation fallback (Z) / the sign select (C)
+  const float* W;
+  unsigned char* S;            // out: P3 planes of S, rows = T, K = out_f
+  const float* rs;             // optional per-sample factor on R
+  int64_t rs_stride;
   int rps;
+  // C-pass epilogue
+  float* out;
 };
 
-// ------------------------------------------------------------------------------------------------
-// Z-pass: S = sd(R f, ((Y - b) + |X||W|^T) / 2), written as bf16 planes [T][Nn/32][3][32]
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads, 2) void zpass_x6_kernel(
-    const unsigned short* __restrict__ Xs, const unsigned short* __restrict__ Ws, const float* __restrict__ X,
-    const float* __restrict__ W, const float* __restrict__ R, const float* __restrict__ Y, const float* __restrict__ bias,
-    unsigned short* __restrict__ Ss, int64_t T, int K, int Nn, int nbn, RowScale rs) {
-  constexpr int BN = 128;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* At = smem;
-  unsigned char* Bt = smem + BM * LROW;
-  const int tile = blockIdx.x;
-  const int64_t row0 = (int64_t)(tile / nbn) * BM;
-  const int col0 = (tile % nbn) * BN;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nk = K / BK;
-  const int64_t rowbytes = (int64_t)(K / 32) * ROWB;
+__device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
-  u32x4 ra[6], rb[6];
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
-  const unsigned char* ap = At + (wm * 64 + lr) * LROW + kh * 16;
-  const unsigned char* bp = Bt + (wn * 64 + lr) * LROW + kh * 16;
-
-  load_planes<BM>(ra, Xs, T, rowbytes, row0, 0);
-  load_planes<BN>(rb, Ws, Nn, rowbytes, col0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    store_planes<BM>(At, ra);
-    store_planes<BN>(Bt, rb);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      load_planes<BM>(ra, Xs, T, rowbytes, row0, kt + 1);
-      load_planes<BN>(rb, Ws, Nn, rowbytes, col0, kt + 1);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          a[i][q] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LROW + q * 64 + s * 32);
-          b[i][q] = *reinterpret_cast<const bf16x8*>(bp + i * 32 * LROW + q * 64 + s * 32);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mma_x6(a[mi], b[ni], acc[mi][ni]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // epilogue: 32x32 block layout col = lr, row = (e & 3) + 8 (e >> 2) + 4 kh
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int gc = col0 + wn * 64 + ni * 32 + lr;
-      const int64_t gr0 = row0 + wm * 64 + mi * 32 + 4 * kh;
-      float rr[16], yy[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t gr = min(gr0 + (e & 3) + 8 * (e >> 2), T - 1);
-        rr[e] = R[gr * Nn + gc];
-        yy[e] = Y[gr * Nn + gc];
-        if (rs.s) rr[e] = rr[e] * rs.s[(gr / rs.rps) * rs.stride];
-      }
-      const float bb = bias ? bias[gc] : 0.0f;
-      unsigned short* sp = Ss + (int64_t)(gc >> 5) * 96 + (gc & 31);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t gr = gr0 + (e & 3) + 8 * (e >> 2);
-        if (gr < T) {
-          const float a_abs = acc[mi][ni][e];
-          float z = 0.5f * ((yy[e] - bb) + a_abs);
-          if (!(z > kCancelTol * a_abs)) z = exact_z(X + gr * K, W + (int64_t)gc * K, K);
-          unsigned short p[3];
-          split3(te_sd(rr[e], z), p);
-          unsigned short* d = sp + gr * (int64_t)(Nn / 32) * 96;
-          d[0] = p[0];
-          d[32] = p[1];
-          d[64] = p[2];
-        }
-      }
-    }
+__device__ __forceinline__ void swap_halves(unsigned& lo_keep, unsigned& hi_keep) {
+  // after the call: lanes 0-31 hold {own lo_keep, partner's lo_keep}; lanes 32-63 hold {partner's hi_keep, own hi_keep}
+  // (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second)
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(lo_keep, hi_keep, false, false);
+  lo_keep = r[0];
+  hi_keep = r[1];
 }
 
 // ------------------------------------------------------------------------------------------------
-// C-pass: out = X+ . (S W+) + X- . (S W-) ; S planes [T][K/32][3][32] (K = out_f), W+^T / W-^T planes [Nn][K/32][3][32]
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads, 2) void cpass_x6_kernel(
-    const unsigned short* __restrict__ Ss, const unsigned short* __restrict__ Wp, const unsigned short* __restrict__ Wn,
-    const float* __restrict__ X, float* __restrict__ out, int64_t T, int K, int Nn, int nbn) {
-  constexpr int BN = 64;
+template <int WM, int MODE>
+__global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
+  constexpr int NW = 4 * WM;                         // waves
+  constexpr int G = (MODE == MODE_Z) ? 3 : 6;        // pieces of one A group (32 rows [x 2 signs]) per K16 step
+  constexpr int NPA = 12 * WM, NPB = 24;             // 1-KiB pieces of one stage: weight side, activation side
+  constexpr int NP = NPA + NPB;
+  constexpr int PBW = NPB / 3 / NW;                  // activation-side 32-row blocks each wave stages (2 or 1)
+  constexpr int STAGE = NP * kFrag;
+  constexpr int GROUPS = NPA / G;                    // A groups per tile: 4 WM (Z) or 2 WM (C)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* At = smem;
-  unsigned char* Pt = smem + BM * LROW;
-  unsigned char* Nt = Pt + BN * LROW;
-  const int tile = blockIdx.x;
-  const int64_t row0 = (int64_t)(tile / nbn) * BM;
-  const int col0 = (tile % nbn) * BN;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nk = K / BK;
-  const int64_t rowbytes = (int64_t)(K / 32) * ROWB;
 
-  u32x4 ra[6], rp[3], rn[3];
-  f32x16 accp[2], accn[2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      accp[mi][e] = 0.0f;
-      accn[mi][e] = 0.0f;
-    }
-  const unsigned char* ap = At + (wm * 64 + lr) * LROW + kh * 16;
-  const unsigned char* pp = Pt + (wn * 32 + lr) * LROW + kh * 16;
-  const unsigned char* np = Nt + (wn * 32 + lr) * LROW + kh * 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lane16 = lane * 16;
 
-  load_planes<BM>(ra, Ss, T, rowbytes, row0, 0);
-  load_planes<BN>(rp, Wp, Nn, rowbytes, col0, 0);
-  load_planes<BN>(rn, Wn, Nn, rowbytes, col0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    store_planes<BM>(At, ra);
-    store_planes<BN>(Pt, rp);
-    store_planes<BN>(Nt, rn);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      load_planes<BM>(ra, Ss, T, rowbytes, row0, kt + 1);
-      load_planes<BN>(rp, Wp, Nn, rowbytes, col0, kt + 1);
-      load_planes<BN>(rn, Wn, Nn, rowbytes, col0, kt + 1);
+  // ---- this workgroup's range of the (tile, K-step) space: whole tiles per XCD, equal ranges inside one ----
+  const int bid = blockIdx.x, spx = gridDim.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nks = p.nks;
+  const int tiles = p.ntm * p.ntn;
+  const int tx0 = (int)((int64_t)tiles * xcd / 8), tx1 = (int)((int64_t)tiles * (xcd + 1) / 8);
+  const int64_t iters = (int64_t)(tx1 - tx0) * nks;
+  auto cut = [&](int s) -> int64_t {
+    int64_t b = iters * s / spx;
+    const int r = (int)(b % nks);
+    if (r < kMinFrag) b -= r;
+    else if (nks - r < kMinFrag) b += nks - r;
+    return b;
+  };
+  const int64_t ib = cut(slot), ie = cut(slot + 1);
+  if (ib >= ie) return;
+  const int f_tile = (int)(ib / nks), kb = (int)(ib - (int64_t)f_tile * nks);
+  const int l_tile = (int)((ie - 1) / nks), ke = (int)(ie - (int64_t)l_tile * nks);
+  const bool tail = kb > 0;                                            // first tile: its head belongs to slot - 1
+  const bool head = (ke < nks) && !(f_tile == l_tile && tail);         // last tile: its tail belongs to slot + 1
+  const int full0 = tail ? f_tile + 1 : f_tile, full1 = (ke < nks) ? l_tile - 1 : l_tile;
+  const int nseq = (head ? 1 : 0) + (full1 >= full0 ? full1 - full0 + 1 : 0) + (tail ? 1 : 0);
+
+  float* my_part = p.partial + (size_t)bid * (256 * WM) * 128;
+  const float* in_part = p.partial + (size_t)(bid - 8) * (256 * WM) * 128;
+
+  for (int seq = 0; seq < nseq; ++seq) {
+    int tile, k0, k1;
+    if (head && seq == 0) {
+      tile = l_tile, k0 = 0, k1 = ke;
+    } else if (tail && seq == nseq - 1) {
+      tile = f_tile, k0 = kb, k1 = (f_tile == l_tile) ? ke : nks;
+    } else {
+      tile = full0 + seq - (head ? 1 : 0), k0 = 0, k1 = nks;
     }
+    tile += tx0;
+    const int tn = tile / p.ntm, tm = tile - tn * p.ntm;
+
+    // ---- what this wave stages per step: the three planes of ONE weight-side 32-row block [one sign] and of PBW
+    //      activation-side blocks -- each 3 KiB contiguous in memory and in the stage; wave-uniform pointers ----
+    const unsigned char* srcA;
+    if constexpr (MODE == MODE_Z)
+      srcA = p.A + (int64_t)(tm * GROUPS + wave) * p.a_group_stride + (int64_t)k0 * kRB;
+    else
+      srcA = p.A + (int64_t)(tm * GROUPS + (wave >> 1)) * p.a_group_stride + (int64_t)k0 * (2 * kRB) + (wave & 1) * kRB;
+    const unsigned char* srcB[PBW];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a[2][3], bpos[3], bneg[3];
+    for (int u = 0; u < PBW; ++u) {
+      const int cb = min(tn * 8 + wave * PBW + u, p.ncb - 1);
+      srcB[u] = p.B + (int64_t)cb * p.b_rb_stride + (int64_t)k0 * kRB;
+    }
+    unsigned char* const ldsA = smem + wave * kRB;
+    unsigned char* const ldsB = smem + NPA * kFrag + wave * (PBW * kRB);
+    auto stage_in = [&](int stg) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        a[0][q] = *reinterpret_cast<const bf16x8*>(ap + q * 64 + s * 32);
-        a[1][q] = *reinterpret_cast<const bf16x8*>(ap + 32 * LROW + q * 64 + s * 32);
-        bpos[q] = *reinterpret_cast<const bf16x8*>(pp + q * 64 + s * 32);
-        bneg[q] = *reinterpret_cast<const bf16x8*>(np + q * 64 + s * 32);
+      for (int q = 0; q < 3; ++q) glds16(srcA + q * kFrag + lane16, ldsA + stg * STAGE + q * kFrag);
+#pragma unroll
+      for (int u = 0; u < PBW; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) glds16(srcB[u] + q * kFrag + lane16, ldsB + stg * STAGE + (u * 3 + q) * kFrag);
+      srcA += G * kFrag;
+#pragma unroll
+      for (int u = 0; u < PBW; ++u) srcB[u] += kRB;
+    };
+
+    f32x16 acc[4][2];
+    if (k0 > 0) {
+      // the head of this tile was computed by the workgroup 8 below: wait for its accumulators, continue its chain
+      if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(p.flags + bid - 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > kSpinLimit) {
+            __hip_atomic_store(p.flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.flags + bid - 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      const f32x4* ip = reinterpret_cast<const f32x4*>(in_part) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        accp[mi] = mma_x6(a[mi], bpos, accp[mi]);
-        accn[mi] = mma_x6(a[mi], bneg, accn[mi]);
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 v = ip[c * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][ni][4 * c + e] = v[e];
+          }
+          ip += 4 * 64;
+          asm volatile("" : "+v"(ip));      // one running pointer, not 32 precomputed ones
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+    }
+
+    // ---- main loop: stage ks + 1 lands while stage ks is multiplied ----
+    stage_in(0);
+    int st = 0;
+    for (int ks = k0; ks < k1; ++ks) {
+      // hipcc does not wait for direct-to-LDS loads at a barrier: this step's stage has landed (all waves) after ...
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();           // ... and the other stage is free again (everybody finished the previous step's reads)
+      if (ks + 1 < k1) stage_in(st ^ 1);
+      const unsigned char* sA = smem + st * STAGE + wm * (4 * kRB) + lane16;
+      const unsigned char* sB = smem + st * STAGE + NPA * kFrag + wn * (2 * kRB) + lane16;
+      bf16x8 a[4][3], b[2][3];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[ni][q] = *reinterpret_cast<const bf16x8*>(sB + ni * kRB + q * kFrag);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[mi][q] = *reinterpret_cast<const bf16x8*>(sA + mi * kRB + q * kFrag);
+      // six partial products per block, smallest first; four independent accumulators between dependent MFMAs
+      constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int q6 = 0; q6 < 6; ++q6)
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const int mi = 2 * hh + m2;
+              acc[mi][ni] = TE_MFMA_BF16(a[mi][PA[q6]], b[ni][PB[q6]], acc[mi][ni]);
+            }
+      st ^= 1;
+    }
+
+    if (k1 < nks) {
+      // ---- publish the accumulators of a cut tile (guide: plain stores -> vmcnt(0) -> barrier -> release -> flag) ----
+      f32x4* op = reinterpret_cast<f32x4*>(my_part) + (size_t)wave * 32 * 64 + lane;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * c + e];
+            op[c * 64] = v;
+          }
+          op += 4 * 64;
+          asm volatile("" : "+v"(op));
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      continue;
     }
-  }
+
+    // ---- epilogue.  32x32 block (mi, ni): lane (tc = lane & 31, h = lane >> 5) holds activation row t and, for
+    //      g = 0..3, weight rows 8 g + 4 h + (0..3) in acc[4 g .. 4 g + 3] ----
+    const int tc = lane & 31, h = lane >> 5;
+    if constexpr (MODE == MODE_Z) {
+      const int nksS = p.out_f >> 4;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int gc = col0 + wn * 32 + lr;
-    const int64_t gr0 = row0 + wm * 64 + mi * 32 + 4 * kh;
-    float xv[16];
+      for (int ni = 0; ni < 2; ++ni) {
+        const int cb = tn * 8 + wn * 2 + ni;
+        if (cb >= p.ncb) continue;
+        const int64_t t = (int64_t)cb * 32 + tc;
+        const bool live = t < p.T;
+        const int64_t tl = live ? t : p.T - 1;
+        float f = 1.0f;
+        if (p.rs) f = p.rs[(tl / p.rps) * p.rs_stride];
+        const float* Rrow = p.R + tl * p.out_f;
+        const float* Yrow = p.Y + tl * p.out_f;
+        unsigned char* Srow = p.S + (int64_t)cb * nksS * kRB + tc * 16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) xv[e] = X[min(gr0 + (e & 3) + 8 * (e >> 2), T - 1) * Nn + gc];
+        for (int mi = 0; mi < 4; ++mi) {
+          const int j0 = (tm * (4 * WM) + wm * 4 + mi) * 32;
+          f32x4 r4[4], y4[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int64_t gr = gr0 + (e & 3) + 8 * (e >> 2);
-      const float xp = fmaxf(xv[e], 0.0f), xn = fminf(xv[e], 0.0f);
-      if (gr < T) out[gr * Nn + gc] = 1.0f * (xp * accp[mi][e] + xn * accn[mi][e]);
+          for (int g = 0; g < 4; ++g) {
+            r4[g] = *reinterpret_cast<const f32x4*>(Rrow + j0 + 8 * g + 4 * h);
+            y4[g] = *reinterpret_cast<const f32x4*>(Yrow + j0 + 8 * g + 4 * h);
+          }
+          unsigned w[4][3][2];                       // [g][plane][dword]: four bf16 of one plane = weight rows 8g+4h+0..3
+          unsigned bad = 0;                          // elements whose Z needs the cancellation fallback
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + j0 + 8 * g + 4 * h);
+            unsigned pl[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float a_abs = acc[mi][ni][4 * g + c];
+              const float z = 0.5f * ((y4[g][c] - b4[c]) + a_abs);
+              const bool cancel = !(z > kCancelTol * a_abs);
+              bad |= (cancel ? 1u : 0u) << (4 * g + c);
+              float rr = r4[g][c];
+              if (p.rs) rr = rr * f;
+              const float sv = (live && !cancel) ? te_sd(rr, z) : 0.0f;
+              split3(sv, pl[c]);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              w[g][q][0] = pl[0][q] | (pl[1][q] << 16);
+              w[g][q][1] = pl[2][q] | (pl[3][q] << 16);
+            }
+          }
+          // lanes h = 0 end up with the 16-B pieces g = 0, 1 (8 consecutive features each), lanes h = 1 with g = 2, 3
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+              for (int d = 0; d < 2; ++d) swap_halves(w[g][q][d], w[g + 2][q][d]);
+          unsigned char* sp = Srow + (int64_t)((j0 >> 4) + h) * kRB;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {           // c = k-half of the K16 step (j0 / 16 + h)
+              // h = 0: piece g = c is {own w[c], partner's w[c]} = (w[c], w[c + 2]) after the swap
+              // h = 1: piece g = 2 + c is {partner's w[2 + c], own w[2 + c]} = (w[c], w[c + 2]) after the swap
+              u32x4 v = {w[c][q][0], w[c][q][1], w[c + 2][q][0], w[c + 2][q][1]};
+              *reinterpret_cast<u32x4*>(sp + q * kFrag + c * 512) = v;
+            }
+          // rare: (Y - b) and |X||W|^T cancel (nearly every product of the element is negative): the reference's plain
+          // positive-part sum, k-ordered, written over the element's three plane values
+          if (!live) bad = 0;
+          if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 16-B pieces above are in memory first
+#pragma clang loop unroll(disable)
+            for (int e = 0; e < 16; ++e) {
+              if ((bad >> e) & 1u) {
+                const int jj = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
+                const float z = exact_z(p.X + tl * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f);
+                float rr = Rrow[jj];
+                if (p.rs) rr = rr * f;
+                unsigned pl[3];
+                split3(te_sd(rr, z), pl);
+                unsigned short* d = reinterpret_cast<unsigned short*>(Srow + (int64_t)(jj >> 4) * kRB + ((jj >> 3) & 1) * 512) + (jj & 7);
+                d[0] = (unsigned short)pl[0];
+                d[kFrag / 2] = (unsigned short)pl[1];
+                d[kFrag] = (unsigned short)pl[2];
+              }
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int64_t t = ((int64_t)tn * 8 + wn * 2 + ni) * 32 + tc;
+        if (t >= p.T) continue;
+#pragma unroll
+        for (int il = 0; il < 2; ++il) {
+          const int i0 = (tm * (2 * WM) + wm * 2 + il) * 32;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ib = i0 + 8 * g + 4 * h;
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(p.X + t * p.in_f + ib);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float xp = fmaxf(x4[c], 0.0f), xn = fminf(x4[c], 0.0f);
+              o[c] = 1.0f * (xp * acc[2 * il][ni][4 * g + c] + xn * acc[2 * il + 1][ni][4 * g + c]);
+            }
+            *reinterpret_cast<f32x4*>(p.out + t * p.in_f + ib) = o;
+          }
+        }
+      }
     }
+    __syncthreads();       // every wave is done with the stages before the next fragment's first loads land in them
   }
 }
 
-inline size_t planes_bytes(int64_t rows, int64_t K) { return te_align_up((size_t)rows * (size_t)K * 6, 256); }
+inline size_t planes_bytes(int64_t rows, int64_t K) {
+  return (size_t)te_ceil_div(rows, 32) * 32 * (size_t)K * 6;
+}
+constexpr size_t kPartialBytes = (size_t)512 * 256 * 128 * 4;       // grid x threads x 128 floats, both geometries: 64 MiB
+constexpr size_t kFlagBytes = 4096;                                  // 512 flags + the error word, per pass
+
+inline int pick_wm(int64_t in_f, int64_t out_f) {
+  if (out_f % 256 == 0 && in_f % 128 == 0) return 2;
+  if (out_f % 128 == 0 && in_f % 64 == 0) return 1;
+  return 0;
+}
+
+template <int WM, int MODE>
+int launch_x6(const X6Params& p, hipStream_t stream) {
+  constexpr int NP = 12 * WM + 24;
+  constexpr int lds = 2 * NP * kFrag;
+  static bool configured = false;      // idempotent attribute of the code object (not data-path state)
+  auto kern = x6_kernel<WM, MODE>;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int64_t tiles = (int64_t)p.ntm * p.ntn;
+  const int max_spx = (WM == 2) ? 32 : 64;
+  const int spx = (int)std::min<int64_t>(max_spx, std::max<int64_t>(1, te_ceil_div(tiles, 8)));
+  kern<<<dim3(8 * spx), dim3(256 * WM), lds, stream>>>(p);
+  return TE_OK;
+}
 
 }  // namespace
 
+// ----------------------------------------------------------------------------------------------------------------------
 extern "C" int te_linear_relprop_x6_supported(int64_t T, int64_t in_f, int64_t out_f) {
-  return (T >= 1 && in_f >= 128 && out_f >= 128 && in_f % 128 == 0 && out_f % 128 == 0 && in_f <= (1 << 20) &&
-          out_f <= (1 << 20) && te_ceil_div(T, BM) * (out_f / 64 + in_f / 64) < 0x7fffffff) ? 1 : 0;
+  return (T >= 1 && in_f >= 128 && out_f >= 128 && pick_wm(in_f, out_f) != 0 && in_f <= (1 << 20) && out_f <= (1 << 20) &&
+          T <= (int64_t)1 << 26) ? 1 : 0;
 }
 
-// workspace: |X| planes, |W| planes, W+^T and W-^T planes, S planes
+extern "C" size_t te_linear_x6_weight_planes_bytes(int64_t in_f, int64_t out_f) {
+  if (!te_linear_relprop_x6_supported(1, in_f, out_f)) return 0;
+  // P3 of |W| (rows = out_f, K = in_f) followed by P6 of W+^T / W-^T (rows = in_f, K = out_f)
+  return te_align_up(planes_bytes(out_f, in_f), 256) + te_align_up(2 * planes_bytes(in_f, out_f), 256);
+}
+
+extern "C" int te_linear_x6_prepare_weights_f32(const float* W, int64_t in_f, int64_t out_f, void* planes,
+                                                size_t planes_bytes_, te_stream_t stream_) {
+  if (!W || !planes) return TE_ERR_INVALID_ARG;
+  if (!te_linear_relprop_x6_supported(1, in_f, out_f) || !te_aligned16(W)) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes_ < te_linear_x6_weight_planes_bytes(in_f, out_f) || !te_aligned16(planes)) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned char* pz = (unsigned char*)planes;
+  unsigned char* pc = pz + te_align_up(planes_bytes(out_f, in_f), 256);
+  split_kernel<OP_ABS, false><<<dim3((unsigned)(out_f / 32), (unsigned)te_ceil_div(in_f / 16, 8)), dim3(256), 0, stream>>>(
+      W, pz, out_f, in_f, 3, 0);
+  const dim3 gc((unsigned)(in_f / 32), (unsigned)te_ceil_div(out_f / 16, 8));
+  split_kernel<OP_POS, true><<<gc, dim3(256), 0, stream>>>(W, pc, in_f, out_f, 6, 0);
+  split_kernel<OP_NEG, true><<<gc, dim3(256), 0, stream>>>(W, pc, in_f, out_f, 6, 1);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+extern "C" size_t te_linear_x6_planes_bytes(int64_t rows, int64_t K) {
+  return (rows < 1 || K < 16 || K % 16) ? 0 : planes_bytes(rows, K);
+}
+
+extern "C" int te_linear_x6_split_abs_f32(const float* X, int64_t rows, int64_t K, void* planes, size_t planes_bytes_,
+                                          te_stream_t stream_) {
+  if (!X || !planes || rows < 1) return TE_ERR_INVALID_ARG;
+  if (K < 16 || K % 16 || !te_aligned16(X) || rows > ((int64_t)1 << 26)) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes)) return TE_ERR_WORKSPACE;
+  split_kernel<OP_ABS, false><<<dim3((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8)), dim3(256), 0,
+                                (hipStream_t)stream_>>>(X, (unsigned char*)planes, rows, K, 3, 0);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// workspace: |X| planes, S planes, the accumulators of cut tiles, flags (Z-pass, C-pass)
 extern "C" size_t te_linear_relprop_x6_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f) {
   if (!te_linear_relprop_x6_supported(T, in_f, out_f)) return 0;
-  return planes_bytes(T, in_f) + 3 * planes_bytes(out_f, in_f) + planes_bytes(T, out_f);
+  return te_align_up(planes_bytes(T, in_f), 256) + te_align_up(planes_bytes(T, out_f), 256) + kPartialBytes + 2 * kFlagBytes;
 }
 
 extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
-                                        int64_t rows_per_sample, const float* X, const float* W, const float* Y,
-                                        const float* bias, float* out, int64_t T, int64_t in_f, int64_t out_f, void* ws,
-                                        size_t ws_bytes, te_stream_t stream_) {
-  if (!R || !X || !W || !Y || !out || T <= 0) return TE_ERR_INVALID_ARG;
+                                        int64_t rows_per_sample, const float* X, const float* W, const void* w_planes,
+                                        const void* x_planes, const float* Y, const float* bias, float* out, int64_t T,
+                                        int64_t in_f, int64_t out_f, int flags, void* ws, size_t ws_bytes,
+                                        te_stream_t stream_) {
+  if (!R || !X || !W || !w_planes || !Y || !out || T <= 0) return TE_ERR_INVALID_ARG;
   if (!te_linear_relprop_x6_supported(T, in_f, out_f)) return TE_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < te_linear_relprop_x6_workspace_bytes(T, in_f, out_f) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
-  if (!te_aligned16(X) || !te_aligned16(W)) return TE_ERR_UNSUPPORTED;
+  if (!te_aligned16(X) || !te_aligned16(W) || !te_aligned16(R) || !te_aligned16(Y) || !te_aligned16(out) ||
+      !te_aligned16(w_planes) || (bias && !te_aligned16(bias)) || (x_planes && !te_aligned16(x_planes)))
+    return TE_ERR_UNSUPPORTED;
   if (r_scale && (rows_per_sample <= 0 || rows_per_sample > 0x7fffffff || T % rows_per_sample)) return TE_ERR_INVALID_ARG;
+  const int phases = (flags & TE_X6_PHASE_MASK) ? (flags & TE_X6_PHASE_MASK) : TE_X6_PHASE_MASK;
   hipStream_t stream = (hipStream_t)stream_;
-  unsigned char* p = (unsigned char*)ws;
-  unsigned short* Xs = (unsigned short*)p;
-  p += planes_bytes(T, in_f);
-  unsigned short* Was = (unsigned short*)p;
-  p += planes_bytes(out_f, in_f);
-  unsigned short* Wps = (unsigned short*)p;      // rows = in_f, K = out_f
-  p += planes_bytes(out_f, in_f);
-  unsigned short* Wns = (unsigned short*)p;
-  p += planes_bytes(out_f, in_f);
-  unsigned short* Ss = (unsigned short*)p;
-  auto blocks = [](int64_t rows, int64_t K) { return dim3((unsigned)te_ceil_div(rows * (K / 8), 256)); };
-  split_kernel<OP_ABS, false><<<blocks(T, in_f), dim3(256), 0, stream>>>(X, Xs, T, in_f);
-  split_kernel<OP_ABS, false><<<blocks(out_f, in_f), dim3(256), 0, stream>>>(W, Was, out_f, in_f);
-  split_kernel<OP_POS, true><<<blocks(in_f, out_f), dim3(256), 0, stream>>>(W, Wps, in_f, out_f);
-  split_kernel<OP_NEG, true><<<blocks(in_f, out_f), dim3(256), 0, stream>>>(W, Wns, in_f, out_f);
-  const int nbm = (int)te_ceil_div(T, BM);
-  {
-    const int nbn = (int)(out_f / 128);
-    zpass_x6_kernel<<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), (size_t)(BM + 128) * LROW, stream>>>(
-        Xs, Was, X, W, R, Y, bias, Ss, T, (int)in_f, (int)out_f, nbn, RowScale{r_scale, r_scale_stride, (int)rows_per_sample});
+  unsigned char* q = (unsigned char*)ws;
+  unsigned char* Xs = q;
+  q += te_align_up(planes_bytes(T, in_f), 256);
+  unsigned char* Ss = q;
+  q += te_align_up(planes_bytes(T, out_f), 256);
+  float* partial = (float*)q;
+  q += kPartialBytes;
+  unsigned* flag_words = (unsigned*)q;
+  const unsigned char* wz = (const unsigned char*)w_planes;
+  const unsigned char* wc = wz + te_align_up(planes_bytes(out_f, in_f), 256);
+
+  if (phases & TE_X6_PHASE_SPLIT) {
+    hipError_t me = hipMemsetAsync(flag_words, 0, 2 * kFlagBytes, stream);
+    if (me != hipSuccess) return (int)me;
   }
-  {
-    const int nbn = (int)(in_f / 64);
-    cpass_x6_kernel<<<dim3((unsigned)(nbm * nbn)), dim3(kThreads), (size_t)(BM + 128) * LROW, stream>>>(
-        Ss, Wps, Wns, X, out, T, (int)out_f, (int)in_f, nbn);
+  if (!x_planes) {
+    if (phases & TE_X6_PHASE_SPLIT) {
+      int rc = te_linear_x6_split_abs_f32(X, T, in_f, Xs, planes_bytes(T, in_f), stream_);
+      if (rc != TE_OK) return rc;
+    }
+    x_planes = Xs;
+  }
+  int wm = pick_wm(in_f, out_f);
+  if ((flags & 3) == TE_X6_TILE_128 && wm == 2) wm = 1;      // 128-row weight tiles, two workgroups per CU
+  if ((flags & ~0x1f) != 0 || (flags & 3) == 3) return TE_ERR_INVALID_ARG;
+  X6Params p{};
+  p.T = T;
+  p.in_f = (int)in_f;
+  p.out_f = (int)out_f;
+  p.ncb = (int)te_ceil_div(T, 32);
+  p.ntn = (int)te_ceil_div(T, kTileT);
+  p.partial = partial;
+  p.R = R;
+  p.Y = Y;
+  p.bias = bias;
+  p.X = X;
+  p.W = W;
+  p.S = Ss;
+  p.rs = r_scale;
+  p.rs_stride = r_scale_stride;
+  p.rps = (int)(r_scale ? rows_per_sample : 1);
+  p.out = out;
+  int rc;
+  if (phases & TE_X6_PHASE_Z) {   // Z-pass: D[j][t] = sum_k |W|[j][k] |X|[t][k]
+    p.A = wz;
+    p.B = (const unsigned char*)x_planes;
+    p.nks = (int)(in_f / 16);
+    p.a_group_stride = (int64_t)p.nks * kRB;
+    p.b_rb_stride = (int64_t)p.nks * kRB;
+    p.ntm = (int)(out_f / (128 * wm));
+    p.flags = flag_words;
+    rc = (wm == 2) ? launch_x6<2, MODE_Z>(p, stream) : launch_x6<1, MODE_Z>(p, stream);
+    if (rc != TE_OK) return rc;
+  }
+  if (phases & TE_X6_PHASE_C) {   // C-pass: D[(i, +-)][t] = sum_j W+-[j][i] S[t][j]
+    p.A = wc;
+    p.B = Ss;
+    p.nks = (int)(out_f / 16);
+    p.a_group_stride = (int64_t)p.nks * 2 * kRB;
+    p.b_rb_stride = (int64_t)p.nks * kRB;
+    p.ntm = (int)(in_f / (64 * wm));
+    p.flags = flag_words + kFlagBytes / 4;
+    rc = (wm == 2) ? launch_x6<2, MODE_C>(p, stream) : launch_x6<1, MODE_C>(p, stream);
+    if (rc != TE_OK) return rc;
   }
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
+}
+
+// 1 if a bounded wait of the last te_linear_relprop_x6_f32 call on this workspace expired (a predecessor workgroup never
+// published its accumulators): the result of that call is invalid.  Synchronises the stream.
+extern "C" int te_linear_relprop_x6_check(const void* ws, int64_t T, int64_t in_f, int64_t out_f, te_stream_t stream_) {
+  if (!ws || !te_linear_relprop_x6_supported(T, in_f, out_f)) return TE_ERR_INVALID_ARG;
+  const unsigned char* q = (const unsigned char*)ws + te_align_up(planes_bytes(T, in_f), 256) +
+                           te_align_up(planes_bytes(T, out_f), 256) + kPartialBytes;
+  unsigned host[2 * kFlagBytes / 4];
+  hipError_t e = hipMemcpyAsync(host, q, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream_);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream_);
+  if (e != hipSuccess) return (int)e;
+  // error words sit at index grid (<= 512) of each pass's flag array; any non-zero word after a completed call is an error
+  for (unsigned i = 0; i < 2 * kFlagBytes / 4; ++i)
+    if (host[i]) return 1;
+  return 0;
 }

@@ -111,17 +111,43 @@ USE_FORWARD_OUTPUT = True
 USE_FORWARD_PRODUCTS = True
 
 
-# OPT-IN (round 2 study): the three products of the rule on bf16 MFMAs at fp32 accuracy (every fp32
-# operand = the exact sum of three bf16 parts, the six partial products above 2^-24 kept), csrc/te_linear_x6.hip.
-# Default off: TE_LINEAR_X6=1 or ops.USE_LINEAR_X6 = True.
-USE_LINEAR_X6 = os.environ.get("TE_LINEAR_X6", "0") not in ("", "0")
+# Linear.relprop (variant ours, alpha = 1, cached forward output) on bf16 MFMAs at fp32 accuracy: every fp32 operand = the
+# exact sum of three bf16 parts, the six partial products above 2^-24 kept, fp32 accumulation (csrc/te_linear_x6.hip).
+# DEFAULT since round 3; TE_LINEAR_X6=0 or ops.USE_LINEAR_X6 = False selects the fp32-MFMA kernels
+# of te_linear.hip, which remain the path of variant lrp, alpha != 1, shapes the x6 kernels do not tile, and rules
+# without a cached forward output.
+USE_LINEAR_X6 = os.environ.get("TE_LINEAR_X6", "1") not in ("", "0")
+X6_CHECK = False     # tests: synchronise after every x6 rule and raise if a bounded hand-over wait expired
+X6_TILE = 0          # te_relprop.h TE_X6_TILE_*: 0 auto, 1 = 128-row weight tiles (measurement knob; results are identical)
+TE_X6_PHASE_SPLIT, TE_X6_PHASE_Z, TE_X6_PHASE_C = 4, 8, 16
+
+
+def x6_weight_planes(W: Tensor, cache: Optional[dict] = None) -> Tensor:
+    """bf16 operand planes of a Linear weight for te_linear_relprop_x6_f32, built once per weight version.  `cache` is a
+    dict owned by the layer (rules.Linear keeps one); the entry is keyed on storage address, shape and the tensor's
+    version counter, so an optimiser step or an in-place edit of the weight rebuilds the planes."""
+    out_f, in_f = W.shape
+    key = (W.data_ptr(), W._version, out_f, in_f, str(W.device))
+    if cache is not None:
+        hit = cache.get("x6_planes")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    Wc = _c(W.detach())
+    with _on_device(Wc) as lib:
+        planes = _ws(lib.te_linear_x6_weight_planes_bytes(in_f, out_f), Wc)
+        _lib.check(lib.te_linear_x6_prepare_weights_f32(_ptr(Wc), in_f, out_f, _ptr(planes), planes.numel(), _stream(Wc)),
+                   "te_linear_x6_prepare_weights_f32")
+    if cache is not None:
+        cache["x6_planes"] = (key, planes)
+    return planes
 
 
 def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant="ours",
-                   Y: Optional[Tensor] = None, bias: Optional[Tensor] = None) -> Tensor:
+                   Y: Optional[Tensor] = None, bias: Optional[Tensor] = None, cache: Optional[dict] = None) -> Tensor:
     """Linear.relprop: R [..., out], X [..., in], W [out, in] -> [..., in].
     Y [..., out] (optional) is the forward output F.linear(X, W, bias) the rule module cached as self.Y; with it
-    (variant ours, alpha = 1) the Z-pass needs one product instead of two."""
+    (variant ours, alpha = 1) the Z-pass needs one product instead of two.  cache: a dict owned by the layer, where the
+    bf16 operand planes of W are kept between calls (x6_weight_planes)."""
     out_f, in_f = W.shape
     lead = X.shape[:-1]
     R, r_scale = _split_deferred(R)
@@ -145,14 +171,34 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
         bc = None if bias is None else _c(bias.detach())
         if Yc.shape[0] != T:
             raise _lib.TeError(f"Linear.relprop: Y has {Yc.shape[0]} rows, X has {T}")
-    if (fwd and USE_LINEAR_X6 and Yc.data_ptr() % 16 == 0
+    if (fwd and USE_LINEAR_X6 and Yc.data_ptr() % 16 == 0 and (bc is None or bc.data_ptr() % 16 == 0)
             and _lib.load().te_linear_relprop_x6_supported(T, in_f, out_f)):
+        planes = x6_weight_planes(Wc, cache)
         with _on_device(Xc) as lib:
             ws = _ws(lib.te_linear_relprop_x6_workspace_bytes(T, in_f, out_f), Xc)
-            with _timed("linear_x6", 2.0 * T * (3 * in_f) * out_f, 4.0 * (3 * T * in_f + 2 * T * out_f) + 6.0 * 2 * T * out_f):
-                _lib.check(lib.te_linear_relprop_x6_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc), _ptr(Yc),
-                                                        _ptr(bc), _ptr(out), T, in_f, out_f, _ptr(ws), ws.numel(),
-                                                        _stream(Xc)), "te_linear_relprop_x6_f32")
+
+            def call(flags):
+                _lib.check(lib.te_linear_relprop_x6_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc), _ptr(planes),
+                                                        None, _ptr(Yc), _ptr(bc), _ptr(out), T, in_f, out_f,
+                                                        X6_TILE | flags, _ptr(ws), ws.numel(), _stream(Xc)),
+                           "te_linear_relprop_x6_f32")
+            if KERNEL_TIMER is None:
+                call(0)
+            else:
+                # bench.py roofline probe: the three phases one by one so that each is bracketed by HIP events.
+                # flops = the bf16 MFMA work EXECUTED (six partial products per fp32 product); bytes = algorithmic
+                gemm = 2.0 * T * in_f * out_f
+                with _timed("linear_x6_split", 0.0, 10.0 * T * in_f):
+                    call(TE_X6_PHASE_SPLIT)
+                with _timed("linear_x6_zpass", 6.0 * gemm, 6.0 * (T * in_f + in_f * out_f + T * out_f) + 8.0 * T * out_f):
+                    call(TE_X6_PHASE_Z)
+                with _timed("linear_x6_cpass", 12.0 * gemm, 6.0 * (T * out_f + 2 * in_f * out_f) + 8.0 * T * in_f):
+                    call(TE_X6_PHASE_C)
+            if X6_CHECK:
+                rc = lib.te_linear_relprop_x6_check(_ptr(ws), T, in_f, out_f, _stream(Xc))
+                if rc != 0:
+                    raise _lib.TeError(f"te_linear_relprop_x6_f32({T},{in_f},{out_f}): a workgroup waited in vain for the "
+                                       f"accumulators of a shared tile (status {rc}); the result is invalid")
         return out.reshape(*lead, in_f)
     if KERNEL_TIMER is not None and fast_ok:
         # bench.py roofline probe: same two kernels, launched one by one so that each launch can be

@@ -124,6 +124,15 @@ class Tanh(nn.Tanh, RelProp):
 
 
 # ------------------------------------------------------------------------------------------ hot path
+def x6_cache(module) -> dict:
+    """Per-layer store of derived operands that outlive one relprop call (the bf16 planes of the weight,
+    ops.x6_weight_planes); not part of the state dict."""
+    c = module.__dict__.get("_te_cache")
+    if c is None:
+        c = module.__dict__["_te_cache"] = {}
+    return c
+
+
 class Linear(nn.Linear, RelProp):
     """layers_ours.py:207-230 / layers_lrp.py:188-211 -> te_linear_relprop_f32."""
 
@@ -134,7 +143,7 @@ class Linear(nn.Linear, RelProp):
         if Y is not None and Y.shape[:-1] != self.X.shape[:-1]:
             Y = None
         return ops.linear_relprop(R, self.X, self.weight.detach(), alpha=alpha, variant=self.variant, Y=Y,
-                                  bias=self.bias)
+                                  bias=self.bias, cache=x6_cache(self))
 
 
 class Add(RelProp):

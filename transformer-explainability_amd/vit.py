@@ -193,13 +193,13 @@ def make_vit_module(L):
             slots = cam_qkv.view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)          # [3][B,H,N,D] views
             var = self.matmul2.variant
             cam1, cam_v = ops.matmul_relprop_av(r_heads, attn, v, out_scale=0.5, cam_v_out=slots[2], variant=var,
-                                                z=getattr(self.matmul2, "Y", None))
+                                                z=R_ours._cached_y(self.matmul2))
             self.save_v_cam(cam_v)
             self.save_attn_cam(cam1)
             if getattr(self, "_stop_after_attn_cam", False):
                 raise L.StopRelprop()
             ops.matmul_relprop_qk(cam1, q, k, out_scale=0.5, cam_q_out=slots[0], cam_k_out=slots[1], variant=var,
-                                  z=getattr(self.matmul1, "Y", None))
+                                  z=R_ours._cached_y(self.matmul1))
             return self.qkv.relprop(cam_qkv, **kwargs)
 
     class Block(nn.Module):
@@ -254,8 +254,10 @@ def make_vit_module(L):
             cls = lambda t: t[:, :1]                                             # noqa: E731
             dfr = ops.USE_DEFERRED_ADD
             c1, c2 = ops.add_relprop(cam_cls, cls(self.add2.X[0]), cls(self.add2.X[1]), variant=var, deferred=dfr)
-            lin = lambda r, m: ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,     # noqa: E731
-                                                  Y=cls(m.Y), bias=m.bias)
+            def lin(r, m):       # the staleness guard of the cached forward output applies here as in Linear.relprop
+                y = R_ours._cached_y(m)
+                return ops.linear_relprop(r, cls(m.X), m.weight.detach(), alpha=alpha, variant=var,
+                                          Y=None if y is None else cls(y), bias=m.bias, cache=R_ours.x6_cache(m))
             c2 = lin(lin(c2, self.mlp.fc2), self.mlp.fc1)
             cam = ops.clone_relprop((c1, c2), cls(self.clone2.X))
             c1, c2 = ops.add_relprop(cam, cls(self.add1.X[0]), cls(self.add1.X[1]), variant=var, deferred=dfr)
