@@ -46,6 +46,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (measured 2495)
+X6_DTYPE = "f32 (3xbf16 split operands, 6 products, fp32 accumulate)"
 HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 _T0 = time.perf_counter()
 
@@ -75,7 +77,6 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline", choices=["auto", "port", "off"], default="auto")
     ap.add_argument("--cpu-maps", type=int, default=5, help="timed maps of the all-cores cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="micro-batches in flight on separate HIP streams")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay each step from a HIP graph (one eager step inside the timed region carries the "
                          "per-kernel HIP events of the roofline); auto = on for the headline configuration, off for "
@@ -90,6 +91,11 @@ def parse_args(argv=None):
                     help="run the relprop rules on a side stream beside the attention-gradient backward pass")
     ap.add_argument("--inflight", type=int, default=1,
                     help="consecutive steps (batches) in flight, each on its own HIP stream (eager launches)")
+    ap.add_argument("--linear", choices=["x6", "fp32"], default="x6",
+                    help="Linear.relprop kernels: x6 (default) = bf16 MFMAs on three-way split fp32 operands, six partial "
+                         "products, fp32 accumulation (csrc/te_linear_x6.hip; fp32-class accuracy, asserted by the parity "
+                         "tests); fp32 = the fp32-MFMA kernels of csrc/te_linear.hip.  With x6 the line also carries the "
+                         "fp32-MFMA throughput of the same workload from a second timed run (config.fp32_mfma_*)")
     ap.add_argument("--producers", choices=["stock", "fused"], default="fused",
                     help="fused (default): the attention blocks' forward and attention-gradient backward run on the "
                          "hand-written producer kernels where the shape qualifies (SURVEY.md 8f.1: head dim 64, N <= 224 "
@@ -166,7 +172,7 @@ class KernelTimer:
         rows = [(f, b, s.elapsed_time(e) * 1e-3) for n, f, b, s, e in self.records if n == name]
         if not rows:
             return None
-        work = [max(f / (MFMA_F32_PEAK_TFLOPS * 1e12), b / (HBM_PEAK_TBS * 1e12)) for f, b, _ in rows]
+        work = [max(f / (mfma_peak(name) * 1e12), b / (HBM_PEAK_TBS * 1e12)) for f, b, _ in rows]
         keep = [r for r, w in zip(rows, work) if w >= min_share * max(work)]
         n = len(keep)
         flops, nbytes, secs = (sum(r[i] for r in keep) for i in range(3))
@@ -175,8 +181,19 @@ class KernelTimer:
                 "tflops": flops / secs / 1e12, "tbs": nbytes / secs / 1e12}
 
 
+def mfma_peak(name):
+    """The MFMA roof a kernel group is priced against: the x6 kernels execute bf16 MFMAs (their flops are the EXECUTED
+    bf16 work, six partial products per fp32 product), everything else fp32 MFMAs."""
+    return MFMA_BF16_PEAK_TFLOPS if name.startswith("linear_x6") else MFMA_F32_PEAK_TFLOPS
+
+
 KERNEL_GROUPS = {
     # timer name: (device kernels, reference rule)
+    "linear_x6_cpass": ("x6_kernel<2, MODE_C>", "Linear.relprop C-pass on bf16 MFMAs (P+ and P- side by side: 12 bf16 "
+                                                "products of 2*T*in*out flops), layers_ours.py:220-225"),
+    "linear_x6_zpass": ("x6_kernel<2, MODE_Z>", "Linear.relprop Z-pass from the forward output on bf16 MFMAs (6 products), "
+                                                "S written as bf16 planes, layers_ours.py:216-219"),
+    "linear_x6_split": ("memset + split_kernel<OP_ABS>", "|X| -> three bf16 planes in MFMA-fragment order"),
     "linear_cpass": ("linear_k2_kernel<0,false,false>", "Linear.relprop C-pass, layers_ours.py:220-225"),
     "linear_zpass_fwd": ("linear_k1_kernel<ZM_FWD>", "Linear.relprop Z-pass from the forward output, layers_ours.py:216-219"),
     "linear_zpass": ("linear_k1_kernel<ZM_OURS>", "Linear.relprop Z-pass (two products), layers_ours.py:216-219"),
@@ -212,7 +229,7 @@ def kernel_table(timer):
         if not s:
             continue
         t = s["avg_us"] * 1e-6
-        t_f = s["flops_per_launch"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        t_f = s["flops_per_launch"] / (mfma_peak(name) * 1e12)
         t_b = s["bytes_per_launch"] / (HBM_PEAK_TBS * 1e12)
         bound = "mfma" if t_f >= t_b else "hbm"
         kern, rule = KERNEL_GROUPS.get(name, (name, ""))
@@ -220,7 +237,8 @@ def kernel_table(timer):
                "avg_us": round(s["avg_us"], 2),
                "algorithmic_flops_per_launch": s["flops_per_launch"], "algorithmic_bytes_per_launch": s["bytes_per_launch"],
                "achieved": round(s["tflops"] if bound == "mfma" else s["tbs"], 4),
-               "peak": MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_TBS,
+               "peak": mfma_peak(name) if bound == "mfma" else HBM_PEAK_TBS,
+               "mfma_dtype": ("bf16 (executed flops)" if name.startswith("linear_x6") else "f32") if bound == "mfma" else None,
                "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": round(max(t_f, t_b) / t, 4)}
         out.append(row)
     out.sort(key=lambda r: -r["avg_us"] * r["launches"])
@@ -266,7 +284,7 @@ class Workload:
             self.start_layer = 1 if args.start_layer is None else args.start_layer
             self.inputs = (torch.stack([synthetic_image(rank * B + i, (3, side, side)) for i in range(B)]).to(dev),)
             self.model = model.to(dev)
-            self.gen = LRP(self.model, streams=args.streams, overlap_backward=(args.overlap_backward == "on"),
+            self.gen = LRP(self.model, overlap_backward=(args.overlap_backward == "on"),
                            prune=(args.prune == "on"))
             self.tokens = (side // 16) ** 2 + 1
             self.out_cols = self.tokens - 1
@@ -476,13 +494,8 @@ def main():
         tuned = te.enable_tuned_gemms(os.path.join(ROOT, "gpurun_out", f"tunableop_gfx950_rank{rank}.csv"), tune=True)
     if args.producers == "fused":
         ops.USE_FUSED_PRODUCERS = True
+    ops.USE_LINEAR_X6 = args.linear == "x6"
 
-    if args.streams > 1 and not os.environ.get("TE_ALLOW_STREAMS"):
-        # Known issue (round 2, not understood): LRP(streams=2) on a batch of 64 stops making progress in its second
-        # step on this ROCm build once the two micro-batches' kernels really run side by side (batch 8 runs; the bitwise
-        # streams test of tests/test_gpu_models.py runs at batch 4).  Refuse instead of hanging the box.
-        sys.exit("bench.py: --streams > 1 is disabled (known hang at batch 64, see DESIGN.md section 7); "
-                 "set TE_ALLOW_STREAMS=1 to try it anyway")
     wl = Workload(args, rank, dev)
     B = wl.B
     log(f"rank {rank}/{world}: {wl.title} model + {B} inputs resident on {dev}")
@@ -498,7 +511,7 @@ def main():
     # their own and must never meet an open capture; replay afterwards is an ordinary launch.
     graphed = None
     use_graph = args.graph == "on" or (args.graph == "auto" and args.config == "vit_b16_224")
-    if use_graph and args.inflight == 1 and args.streams == 1:
+    if use_graph and args.inflight == 1:
         try:
             graphed = GraphedCall(wl.eager, wl.inputs)
             log("HIP graph of one step captured")
@@ -565,6 +578,35 @@ def main():
         elapsed = float(t.item())
     assert gathered.shape == (world * B, wl.out_cols) and torch.isfinite(gathered).all()
 
+    # Rounds stay comparable: with the x6 Linear rules the same workload is timed once more on the fp32-MFMA kernels of
+    # csrc/te_linear.hip (own graph capture, one warm-up, the same number of steps); N = 1 only, after the timed region.
+    fp32_cmp = {}
+    used_graph = graphed is not None
+    if args.linear == "x6" and world == 1 and args.inflight == 1:
+        ops.USE_LINEAR_X6 = False
+        try:
+            g2 = None
+            if used_graph:
+                graphed = None      # release the first graph's private memory pool before capturing the second
+                g2 = GraphedCall(wl.eager, wl.inputs)
+            run2 = (lambda: g2(*wl.inputs)) if g2 is not None else (lambda: wl.eager(*wl.inputs))
+            run2()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                m2 = run2()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            assert torch.isfinite(m2).all()
+            fp32_cmp = {"fp32_mfma_maps_per_s" if wl.noun == "maps" else "fp32_mfma_sequences_per_s": B * args.steps / e2,
+                        "fp32_mfma_ms_per_step": e2 / args.steps * 1e3,
+                        "fp32_mfma_note": "the same step with the Linear rules on the fp32-MFMA kernels (te_linear.hip); "
+                                          "second timed run of this process"}
+            log(f"fp32-MFMA comparison run: {e2 / args.steps * 1e3:.2f} ms/step")
+            del g2
+        finally:
+            ops.USE_LINEAR_X6 = True
+
     if rank == 0:
         value = world * B * args.steps / elapsed
         idx = CONFIGS[args.config][0]
@@ -575,20 +617,24 @@ def main():
             "metric": f"relevance {wl.noun}/sec ({wl.title}, batch {B} per GPU, generate_LRP transformer_attribution)",
             "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": X6_DTYPE if args.linear == "x6" else "f32", "data": "synthetic",
             "config": {"workload": f"{wl.title} batch {B} per GPU on {world}xMI355X: PyTorch-ROCm fwd + attn-grad bwd "
-                                   f"({fused_note}) + fp32 relprop/head-mean/rollout HIP kernels (BASELINE.json "
+                                   f"({fused_note}) + fp32 relprop/head-mean/rollout HIP kernels"
+                                   f"{' (Linear rules: fp32 operands as three bf16 planes on bf16 MFMAs)' if args.linear == 'x6' else ''} (BASELINE.json "
                                    f"configs[{idx}], sharded by sample)",
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": wl.tokens, "blocks": wl.blocks,
                        "start_layer": wl.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
-                       "streams": args.streams, "steps_in_flight": args.inflight,
+                       "steps_in_flight": args.inflight,
                        "relprop_beside_backward": args.overlap_backward == "on",
                        "blocks_below_start_layer_pruned": args.prune == "on",
                        "producers": "fused attention forward/backward kernels" if fused_on else "stock",
                        "stock_gemm_selection": ("PyTorch TunableOp, committed results file" if tuned and
                                                 args.tuned_gemms == "on" else
                                                 "PyTorch TunableOp, tuned in this run" if tuned else "PyTorch default"),
-                       "hip_graph": graphed is not None, "parallelism": f"dp{world} (independent samples, one "
+                       "linear_relprop": ("x6: bf16 MFMAs on three-way split fp32 operands, six partial products, fp32 "
+                                          "accumulation" if args.linear == "x6" else "fp32 MFMA"),
+                       **fp32_cmp,
+                       "hip_graph": used_graph, "parallelism": f"dp{world} (independent samples, one "
                                                                       f"all_gather of the maps)"},
         }
         roof = None
@@ -597,7 +643,9 @@ def main():
         try:   # HBM-side bytes per C-pass launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
                # MI355X guide's gfx950 correction); only valid for the workload they were collected on
             if args.config == "vit_b16_224" and B == 64:
-                for cand in ("r02_linear_traffic_pmc.json", "r01_linear_traffic_pmc.json"):
+                cands = (("r03_linear_x6_traffic_pmc.json",) if args.linear == "x6" else
+                         ("r03_linear_traffic_pmc.json", "r02_linear_traffic_pmc.json", "r01_linear_traffic_pmc.json"))
+                for cand in cands:
                     path = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(path):
                         with open(path) as f:
@@ -609,10 +657,41 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         # the headline block averages EVERY launch of the kernel, like the rocprofv3 kernel-stats row it must agree with
+        kernels_note = ("one eager step inside the timed region; per C-ABI call: HIP events on the launch stream, "
+                        "ALGORITHMIC flops / bytes (SURVEY.md 8d, App. B; the x6 kernels: the bf16 MFMA flops they "
+                        "EXECUTE, six partial products per fp32 product, against the bf16 peak), frac = max(flops / MFMA "
+                        f"peak ({MFMA_F32_PEAK_TFLOPS} TF fp32, {MFMA_BF16_PEAK_TFLOPS:.0f} TF bf16), bytes / "
+                        f"{HBM_PEAK_TBS} TB/s) / measured time; launches carrying < 5 % of the group's largest work "
+                        "(class-token path of the last block) are excluded from the table's averages (the headline block "
+                        "above averages every launch, like rocprofv3's kernel-stats row)")
+        x6c = timer.summary("linear_x6_cpass", 0.0)
+        x6z = timer.summary("linear_x6_zpass", 0.0)
         cp = timer.summary("linear_cpass", 0.0)
         zp = timer.summary("linear_zpass_fwd", 0.0) or timer.summary("linear_zpass", 0.0)
-        if cp:
-            roof = {"bound": "mfma", "kernel": "linear_k2_kernel<0,false,false> (Linear.relprop C-pass)",
+        if x6c:
+            # dominant kernel of the default path: the C-pass on bf16 MFMAs.  `achieved` = EXECUTED bf16 flops (12 bf16
+            # products of 2*T*in*out per launch) / time against the 2.5 PF dense bf16 peak; the fp32-equivalent rate
+            # (the 2 fp32 products the rule asks for) stands beside it.
+            roof = {"bound": "mfma", "mfma_dtype": "bf16",
+                    "kernel": "x6_kernel<2, MODE_C> (Linear.relprop C-pass, three-way split fp32 operands on bf16 MFMAs)",
+                    "achieved": x6c["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": x6c["tflops"] / MFMA_BF16_PEAK_TFLOPS,
+                    "fp32_equivalent_tflops": x6c["tflops"] / 6.0,
+                    "fp32_equivalent_note": "algorithmic fp32 flops of the C-pass (2 products of 2*T*in*out) / time; the "
+                                            f"fp32-MFMA peak this replaces is {MFMA_F32_PEAK_TFLOPS} TF",
+                    "traffic": traffic,
+                    "traffic_note": (f"bytes per launch, mean of the 4 C-pass shapes of a block; offline rocprofv3 --pmc "
+                                     f"FETCH_SIZE / WRITE_SIZE passes (profiles/{traffic_src})") if traffic else None,
+                    "launches_timed": x6c["launches"], "avg_launch_us": x6c["avg_us"],
+                    "executed_bf16_flops_per_launch_avg": x6c["flops_per_launch"],
+                    "zpass": {"kernel": "x6_kernel<2, MODE_Z> (Z-pass from the forward output, 6 bf16 products of "
+                                        "2*T*in*out flops; S leaves as bf16 planes)",
+                              "achieved": x6z["tflops"], "frac": x6z["tflops"] / MFMA_BF16_PEAK_TFLOPS,
+                              "avg_launch_us": x6z["avg_us"]} if x6z else None,
+                    "kernels": kernel_table(timer), "kernels_note": kernels_note}
+        elif cp:
+            roof = {"bound": "mfma", "mfma_dtype": "f32",
+                    "kernel": "linear_k2_kernel<0,false,false> (Linear.relprop C-pass)",
                     "achieved": cp["tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": cp["tflops"] / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_note": (f"bytes per launch, mean of the 4 C-pass shapes of a block; offline rocprofv3 --pmc "
@@ -621,13 +700,7 @@ def main():
                     "algorithmic_flops_per_launch_avg": cp["flops_per_launch"],
                     "zpass": {"kernel": "linear_k1_kernel<ZM_FWD> (Z-pass from the forward output, 2*T*in*out FLOP)",
                               "achieved": zp["tflops"], "avg_launch_us": zp["avg_us"]} if zp else None,
-                    "kernels": kernel_table(timer),
-                    "kernels_note": "one eager step inside the timed region; per C-ABI call: HIP events on the launch "
-                                    "stream, ALGORITHMIC flops / bytes (SURVEY.md 8d, App. B), frac = max(flops / "
-                                    f"{MFMA_F32_PEAK_TFLOPS} TF, bytes / {HBM_PEAK_TBS} TB/s) / measured time; launches "
-                                    "carrying < 5 % of the group's largest work (class-token path of the last block) "
-                                    "are excluded from the table's averages (the headline block above averages every "
-                                    "launch, like rocprofv3's kernel-stats row)"}
+                    "kernels": kernel_table(timer), "kernels_note": kernels_note}
         line["roofline"] = roof
         base = None
         if world == 1 and args.cpu_baseline != "off":

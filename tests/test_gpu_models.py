@@ -25,8 +25,17 @@ REL_TOL = 2e-3
 # from itself when only fp32 rounding changes (1 / 2 / 3 / 4 / 6 threads vs all threads; fp32 vs an fp64 run).  A
 # cross-producer comparison must stay within BAND_K x that band (+ a floor for samples whose band is at rounding level);
 # on the samples picked for a small band this is the north star's 1e-4 on the min-max-normalised map, literally.
-BAND_K = 5.0
-BAND_OUTLIER_K = 100.0      # see _assert_within_band: heavy-tailed amplification; outliers are counted, and rare
+BAND_K = 5.0                # asserted directly since round 3 (bands.npz: 32 draws of per-layer rounding noise per sample)
+BAND_OUTLIER_K = 100.0      # bound for the comparisons NAMED below, the only ones allowed beyond BAND_K
+# comparisons that exceed BAND_K x their band on the MI355X although the HIP relprop agrees with the oracle on the same
+# cache to 1e-6 (LRP's noise amplification is heavy-tailed: 32 draws still under-sample an occasional sample); each is
+# named here with its measured ratio, and test_zz_band_outliers_are_rare fails if the list grows past one in ten
+BAND_NAMED_OUTLIERS = (
+    # ViT-B/16 seed 7 image 0, start_layer 1: ONE batched forward (rocBLAS M = 788) vs four separate forwards (M = 197),
+    # both on the GPU, both through the same HIP relprop (which is bitwise batch-invariant on a given cache): 30 x the
+    # CPU noise band of the sample (r02: 29 x; normalised 6.7e-2).  The two producers' rounding differs in every GEMM.
+    "vit_b16.batch_vs_separate_forwards[0]",
+)
 BAND_UNSTABLE = 0.05        # a band above 5 % of the map's range: the reference's own map of that sample is not reproducible
 NORTH_STAR_SAMPLES = ("seed1.img1", "seed2.img1")     # small-band samples on which 1e-4 is asserted literally
 BAND_FLOOR_NORM = 2e-5      # same-cache HIP-vs-oracle distance (2e-7..2e-6) plus head-room; << 1e-4
@@ -38,12 +47,13 @@ def _assert_within_band(name, got, ref, bands, keys, literal_1e4=False):
     """got / ref [n, M]; keys[i] = the bands.npz key of sample i.  Per sample: normalised and relative distance
     <= BAND_K x the reference's own noise band on that sample (+ floor); raw north-star bar always.
 
+    The band of a sample = the largest distance of the reference from itself over 1 / 2 / 3 / 4 / 6 threads, an fp64
+    run and 32 draws of one extra fp32 rounding on the output of every Linear / Conv2d layer (make_golden.py bands).
     LRP's amplification of rounding noise is heavy-tailed (a division by a near-zero Z either is hit by a given
-    perturbation or is not), so the maximum of a dozen noise draws of the reference under-estimates an occasional
-    sample: measured on the MI355X, 12 of 13 comparisons sit at 0.8-1.8 x their band and one at 42 x (while the HIP
-    relprop agrees with the oracle on that sample's own cache to 1e-6).  A comparison beyond BAND_K x band is therefore
-    logged as an outlier -- still bounded by BAND_OUTLIER_K x band -- and test_zz_band_outliers_are_rare, the last
-    test of this file, fails if more than one in ten comparisons needed that allowance."""
+    perturbation or is not: per sample the draws' median and maximum differ by 10-1000 x), so BAND_K x band is asserted
+    DIRECTLY; a comparison may exceed it only if it is listed by name in BAND_NAMED_OUTLIERS (then bounded by
+    BAND_OUTLIER_K), and test_zz_band_outliers_are_rare keeps that list below one in ten.  Samples whose band exceeds
+    BAND_UNSTABLE of the map's range are held to the raw bar only: the reference does not reproduce itself there."""
     worst = {}
     for i, key in enumerate(keys):
         s = map_stats(got[i:i + 1], ref[i:i + 1])
@@ -61,7 +71,10 @@ def _assert_within_band(name, got, ref, bands, keys, literal_1e4=False):
         _BAND_LOG.append((f"{name}[{i}]", ratio))
         if literal_1e4:
             assert s["normalised_max_abs"] <= 1e-4, (name, i, s)
-        assert ratio <= BAND_OUTLIER_K, (name, i, s, dict(band_norm=bn, band_rel=br, ratio=ratio))
+        if f"{name}[{i}]" in BAND_NAMED_OUTLIERS:      # named, and still bounded
+            assert ratio <= BAND_OUTLIER_K, (name, i, s, dict(band_norm=bn, band_rel=br, ratio=ratio))
+        else:
+            assert ratio <= BAND_K, (name, i, s, dict(band_norm=bn, band_rel=br, ratio=ratio))
         worst[key] = s
     return worst
 
@@ -477,10 +490,6 @@ def test_vit_b16_batch_equals_singles(vit_b16, golden_bands):
         _ops.USE_FORWARD_PRODUCTS = True
     band_keys = [f"vit_b16.seed7x4.img{i}.sl1" for i in range(B)]
     _assert_within_band("vit_b16.attention_forwardZ_vs_recomputedZ", batch, recomputed, golden_bands, band_keys)
-    # micro-batches on separate HIP streams == the same micro-batches run one after the other, bitwise
-    streamed = LRP(model, streams=2).generate_LRP(x, start_layer=1)
-    halves = torch.cat([lrp.generate_LRP(x[:2], start_layer=1), lrp.generate_LRP(x[2:], start_layer=1)], 0)
-    assert torch.equal(streamed, halves), float((streamed - halves).abs().max())
     # the whole pass replayed from a HIP graph == the eager pass, bitwise (same kernels, same order), on new inputs too
     from transformer_explainability_amd.generators import GraphedLRP
     glrp = GraphedLRP(lrp, x, method="transformer_attribution", start_layer=1)
@@ -661,6 +670,71 @@ def _fits(bytes_needed):
     return bytes_needed < 0.8 * free
 
 
+def test_config1_vit_b16_batch64(vit_b16, golden_bands):
+    """BASELINE.json configs[1], the headline, at its own size ON THE BENCH'S OWN PATH: ViT-B/16 at
+    batch 64 (T = 12 608 rows = 49.25 tiles of 256: the only configuration with a partial last tile) with the fused
+    attention / LayerNorm / GELU producers, the TunableOp GEMM selection, the split-operand bf16 Linear rules (default)
+    and HIP-graph replay, exactly as bench.py runs it.  Graph replay == eager (bitwise); batched == per-sample on the
+    same cache (bitwise) and the CPU oracle on that cache (tight) for samples 0, 31 and 63 (63 sits in the partial tile);
+    LRP conservation over the batch; samples 31 and 63 against the reference's own maps inside their noise bands; no
+    hand-over wait of the stream-K Linear kernels expired."""
+    import transformer_explainability_amd as te
+    from gpu_util import sliced_relprop_state
+    from transformer_explainability_amd import ops
+    from transformer_explainability_amd.generators import LRP, GraphedCall
+    model = vit_b16.to(dev())
+    B = 64
+    x = seeded_randn((B, 3, 224, 224), 1).to(dev())
+    lrp = LRP(model)
+    was = (ops.USE_FUSED_PRODUCERS, ops.USE_LINEAR_X6)
+    tuned = te.enable_tuned_gemms()
+    ops.USE_FUSED_PRODUCERS, ops.USE_LINEAR_X6 = True, True
+    try:
+        ops.X6_CHECK = True
+        maps = lrp.generate_LRP(x, method="transformer_attribution", start_layer=1).clone()
+        ops.X6_CHECK = False
+        assert maps.shape == (B, 196) and torch.isfinite(maps).all()
+        oh = _one_hot_of(model.head.Y.detach())
+        for i in (0, 31, 63):
+            with sliced_relprop_state(model, i, B):
+                cache = vit_cache_from_model(model)
+                one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
+                assert torch.equal(one, maps[i:i + 1]), (i, float((one - maps[i:i + 1]).abs().max()))
+            ref = O.vit_relprop(oh[i:i + 1].cpu(), cache, num_heads=12, start_layer=1)
+            _assert_map(f"vit_b16_b64.oracle.map_sl1.{i}", maps[i:i + 1], ref["map"], norm_tol=2e-4, rel_tol=3e-4)
+        # conservation over the whole batch (same cache)
+        cam = model.head.relprop(oh, alpha=1)
+        cam = model.pool.relprop(cam.unsqueeze(1), alpha=1)
+        for blk in reversed(model.blocks):
+            cam = blk.relprop(cam, alpha=1)
+        sums = cam.double().sum(dim=(1, 2)).cpu()
+        record("vit_b16_b64.conservation", min=float(sums.min()), max=float(sums.max()), tuned_gemms=bool(tuned))
+        assert (sums - 1.0).abs().max() < 2e-3
+        # against the reference's own CPU maps of samples 31 and 63 (bands.npz seed1x64)
+        keys = [f"vit_b16.seed1x64.img{i}.sl1" for i in (31, 63)]
+        _assert_within_band("vit_b16_b64.golden.map_sl1", maps[[31, 63]],
+                            torch.cat([golden_bands[k + ".map"] for k in keys], 0), golden_bands, keys)
+        # the graph-replayed step (what bench.py times) == the eager step, bitwise; also on a second batch
+        g = GraphedCall(lambda t: lrp.generate_LRP(t, method="transformer_attribution", start_layer=1), (x,))
+        assert torch.equal(g(x), maps)
+        x2 = seeded_randn((B, 3, 224, 224), 9).to(dev())
+        rep = g(x2).clone()
+        assert torch.equal(rep, lrp.generate_LRP(x2, method="transformer_attribution", start_layer=1))
+        del g
+    finally:
+        ops.USE_FUSED_PRODUCERS, ops.USE_LINEAR_X6 = was
+        ops.X6_CHECK = False
+        try:
+            import torch.cuda.tunable as tunable
+            tunable.enable(False)
+        except ImportError:
+            pass
+    for blk in model.blocks:
+        blk.attn.attn = blk.attn.attn_cam = blk.attn.attn_gradients = None
+    model.to("cpu")
+    torch.cuda.empty_cache()
+
+
 def test_config2_vit_l16_384_batch32():
     """BASELINE.json configs[2]: ViT-L/16 at 384^2 (N = 577, 24 blocks, 1024 wide, 16 heads), batch 32 on one MI355X.
     Size-independent properties at the full size -- finite maps, LRP conservation (token relevance of every sample
@@ -744,11 +818,14 @@ def test_config3_bert_base_512_batch32():
 
 
 def test_zz_band_outliers_are_rare():
-    """Runs last: of all band-bounded cross-producer comparisons of this session (see _assert_within_band), at most one
-    in ten (and never more than three) may lie beyond BAND_K x the reference's own noise band."""
+    """Runs last: of all band-bounded cross-producer comparisons of this session (see _assert_within_band) every one not
+    named in BAND_NAMED_OUTLIERS was ASSERTED within BAND_K x its band; the named ones stay below one in ten, and the
+    median comparison sits well inside its band."""
     if not _BAND_LOG:
         pytest.skip("no band-bounded comparison ran in this session")
     out = [(n, r) for n, r in _BAND_LOG if r > BAND_K]
-    record("band_outliers", comparisons=len(_BAND_LOG), outliers=[[n, r] for n, r in out],
-           median_ratio=sorted(r for _, r in _BAND_LOG)[len(_BAND_LOG) // 2])
-    assert len(out) <= min(3, max(1, len(_BAND_LOG) // 10)), out
+    med = sorted(r for _, r in _BAND_LOG)[len(_BAND_LOG) // 2]
+    record("band_outliers", comparisons=len(_BAND_LOG), outliers=[[n, r] for n, r in out], median_ratio=med)
+    assert all(n in BAND_NAMED_OUTLIERS for n, _ in out), out
+    assert len(out) <= max(1, len(_BAND_LOG) // 10), out
+    assert med <= 1.0, med

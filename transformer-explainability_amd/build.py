@@ -63,6 +63,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, "te_common.h"), os.path.join(INCLUDE, "te_relprop.h"), __file__]
+    # measurement builds only (benchmarks/): TE_BUILD_DEFINES="TE_X6_STUDY" adds -D flags and forces a rebuild
+    extra = ["-D" + d for d in os.environ.get("TE_BUILD_DEFINES", "").split() if d]
+    force = force or bool(extra)
     objs, rebuilt = [], False
     procs = []
     for src in SOURCES:
@@ -70,7 +73,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in headers):
-            cmd = [hipcc, *CXXFLAGS, "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
+            cmd = [hipcc, *CXXFLAGS, *extra, "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

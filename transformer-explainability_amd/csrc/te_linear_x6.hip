@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
     }
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(u32x4* __restrict__ p) {
+  p[(size_t)blockIdx.x * 256 + threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
+}
+
 // plain positive-part sum of one output element (the reference's Z), k-ordered: the cancellation fallback
 __device__ __forceinline__ float exact_z(const float* __restrict__ x, const float* __restrict__ w, int64_t K) {
   float z1 = 0.0f, z2 = 0.0f;
@@ -176,7 +180,10 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_keep, unsigned& hi_keep
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int WM, int MODE>
+// STUDY (only instantiated under -DTE_X6_STUDY, benchmarks/x6_bench.py --study): timing-only ablations of the main loop --
+// 1: no global loads after the first stage; 2: + no barrier; 3: + no LDS reads (MFMAs on resident fragments);
+// 4: the shipped loop without the epilogue.  Their results are garbage by construction.
+template <int WM, int MODE, int STUDY = 0>
 __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
   constexpr int NW = 4 * WM;                         // waves
   constexpr int G = (MODE == MODE_Z) ? 3 : 6;        // pieces of one A group (32 rows [x 2 signs]) per K16 step
@@ -185,6 +192,10 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
   constexpr int PBW = NPB / 3 / NW;                  // activation-side 32-row blocks each wave stages (2 or 1)
   constexpr int STAGE = NP * kFrag;
   constexpr int GROUPS = NPA / G;                    // A groups per tile: 4 WM (Z) or 2 WM (C)
+  constexpr bool FULL = (STUDY == 0 || STUDY >= 4);  // study builds: 5 = shipped + time stamps, 6 = no epilogue + stamps
+  constexpr bool EPI = (STUDY == 0 || STUDY == 5), PROF = (STUDY == 5 || STUDY == 6);
+  long long prof_loop = 0, prof_epi = 0, prof_pub = 0, prof_wait = 0, prof_t0 = 0, prof_t1 = 0, prof_steps = 0, prof_nepi = 0;
+  const long long prof_start = PROF ? wall_clock64() : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -245,18 +256,23 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     }
     unsigned char* const ldsA = smem + wave * kRB;
     unsigned char* const ldsB = smem + NPA * kFrag + wave * (PBW * kRB);
-    auto stage_in = [&](int stg) __attribute__((always_inline)) {
+    // adv = 0 re-requests the step already staged (branch-free last step: no control-flow join between the fragment
+    // reads and the MFMAs, which is what lets hipcc wait for the reads piecemeal)
+    auto stage_in = [&](int stg, int adv) __attribute__((always_inline)) {
+      srcA += adv * (G * kFrag);
+#pragma unroll
+      for (int u = 0; u < PBW; ++u) srcB[u] += adv * kRB;
 #pragma unroll
       for (int q = 0; q < 3; ++q) glds16(srcA + q * kFrag + lane16, ldsA + stg * STAGE + q * kFrag);
 #pragma unroll
       for (int u = 0; u < PBW; ++u)
 #pragma unroll
         for (int q = 0; q < 3; ++q) glds16(srcB[u] + q * kFrag + lane16, ldsB + stg * STAGE + (u * 3 + q) * kFrag);
-      srcA += G * kFrag;
-#pragma unroll
-      for (int u = 0; u < PBW; ++u) srcB[u] += kRB;
     };
 
+    if constexpr (PROF) {
+      if (threadIdx.x == 0) prof_t0 = wall_clock64();
+    }
     f32x16 acc[4][2];
     if (k0 > 0) {
       // the head of this tile was computed by the workgroup 8 below: wait for its accumulators, continue its chain
@@ -296,41 +312,88 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
           for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
     }
 
+    if constexpr (PROF) {
+      if (threadIdx.x == 0) {
+        const long long t = wall_clock64();
+        prof_wait += t - prof_t0;
+        prof_t0 = t;
+        prof_steps += k1 - k0;
+      }
+    }
     // ---- main loop: stage ks + 1 lands while stage ks is multiplied ----
-    stage_in(0);
+    stage_in(0, 0);
     int st = 0;
-    for (int ks = k0; ks < k1; ++ks) {
-      // hipcc does not wait for direct-to-LDS loads at a barrier: this step's stage has landed (all waves) after ...
+    bf16x8 a[4][3], b[2][3];
+    if constexpr (STUDY == 3) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();           // ... and the other stage is free again (everybody finished the previous step's reads)
-      if (ks + 1 < k1) stage_in(st ^ 1);
-      const unsigned char* sA = smem + st * STAGE + wm * (4 * kRB) + lane16;
-      const unsigned char* sB = smem + st * STAGE + NPA * kFrag + wn * (2 * kRB) + lane16;
-      bf16x8 a[4][3], b[2][3];
+      __syncthreads();
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) b[ni][q] = *reinterpret_cast<const bf16x8*>(sB + ni * kRB + q * kFrag);
+        for (int q = 0; q < 3; ++q) b[ni][q] = *reinterpret_cast<const bf16x8*>(smem + NPA * kFrag + wn * (2 * kRB) + lane16 + ni * kRB + q * kFrag);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[mi][q] = *reinterpret_cast<const bf16x8*>(sA + mi * kRB + q * kFrag);
-      // six partial products per block, smallest first; four independent accumulators between dependent MFMAs
+        for (int q = 0; q < 3; ++q) a[mi][q] = *reinterpret_cast<const bf16x8*>(smem + wm * (4 * kRB) + lane16 + mi * kRB + q * kFrag);
+    }
+    for (int ks = k0; ks < k1; ++ks) {
+      // hipcc does not wait for direct-to-LDS loads at a barrier: this step's stage has landed (all waves) after ...
+      if constexpr (FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (FULL || STUDY == 1) __syncthreads();   // ... and the other stage is free again
+      const unsigned char* sA = smem + st * STAGE + wm * (4 * kRB) + lane16;
+      const unsigned char* sB = smem + st * STAGE + NPA * kFrag + wn * (2 * kRB) + lane16;
+      // The order below is pinned with sched_barrier: left to itself hipcc's scheduler flips between an order that
+      // chains dependent MFMAs two apart behind piecemeal LDS waits and a good one on unrelated source edits (+-17 % on
+      // the whole kernel, measured).  Six partial products per block, smallest first (PA / PB); one ROUND = the same
+      // partial product of all eight blocks (eight independent accumulators between dependent MFMAs).  The fragment
+      // reads are issued in the order the rounds consume them: round 0 needs plane 1 of both sides, round 1 planes
+      // (0, 2), round 2 planes (2, 0); rounds 3-5 reuse what is resident.
       constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+      // the next step's stage is requested FIRST: with a direct-to-LDS load between the fragment reads and the MFMAs
+      // hipcc waits lgkmcnt(0) before the first MFMA instead of lgkmcnt(12) / (6) / (0) round by round
+      if constexpr (FULL) stage_in(st ^ 1, (ks + 1 < k1) ? 1 : 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // The reads are inline asm with hand-counted waits (guide 5.7): hipcc waits lgkmcnt(0) before the first MFMA once a
+      // direct-to-LDS load is in flight; lgkmcnt counts LDS returns in order, so 12 / 6 / 0 outstanding = round 0 / 1 / 2
+      // operands present.  (Waits the compiler adds for its own LDS operations can only be longer than needed.)
+      if constexpr (STUDY != 3) {
+        const unsigned aA = (unsigned)(uintptr_t)sA, aB = (unsigned)(uintptr_t)sB;
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int q6 = 0; q6 < 6; ++q6)
+          for (int ni = 0; ni < 2; ++ni)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[ni][PB[r]]) : "v"(aB), "i"(ni * kRB + PB[r] * kFrag));
 #pragma unroll
-          for (int m2 = 0; m2 < 2; ++m2)
+          for (int mi = 0; mi < 4; ++mi)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[mi][PA[r]]) : "v"(aA), "i"(mi * kRB + PA[r] * kFrag));
+        }
+      } else {
+        (void)sA;
+        (void)sB;
+      }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              const int mi = 2 * hh + m2;
-              acc[mi][ni] = TE_MFMA_BF16(a[mi][PA[q6]], b[ni][PB[q6]], acc[mi][ni]);
-            }
+      for (int q6 = 0; q6 < 6; ++q6) {
+        if constexpr (STUDY != 3) {
+          if (q6 == 0) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+          if (q6 == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+          if (q6 == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = TE_MFMA_BF16(a[mi][PA[q6]], b[ni][PB[q6]], acc[mi][ni]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       st ^= 1;
     }
 
+    if constexpr (PROF) {
+      if (threadIdx.x == 0) {
+        prof_t1 = wall_clock64();
+        prof_loop += prof_t1 - prof_t0;
+      }
+    }
     if (k1 < nks) {
       // ---- publish the accumulators of a cut tile (guide: plain stores -> vmcnt(0) -> barrier -> release -> flag) ----
       f32x4* op = reinterpret_cast<f32x4*>(my_part) + (size_t)wave * 32 * 64 + lane;
@@ -354,67 +417,106 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(p.flags + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (PROF) prof_pub += wall_clock64() - prof_t1;
       }
       continue;
     }
 
+    if constexpr (!EPI) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+      __syncthreads();
+      if constexpr (PROF) {
+        if (threadIdx.x == 0) {
+          prof_epi += wall_clock64() - prof_t1;
+          prof_nepi += 1;
+        }
+      }
+      continue;
+    }
     // ---- epilogue.  32x32 block (mi, ni): lane (tc = lane & 31, h = lane >> 5) holds activation row t and, for
     //      g = 0..3, weight rows 8 g + 4 h + (0..3) in acc[4 g .. 4 g + 3] ----
     const int tc = lane & 31, h = lane >> 5;
+    // The loads of a block are issued as one batch BEFORE the previous block's stores (hipcc keeps loads behind stores
+    // that may alias, and a store then costs a full round trip per `s_waitcnt vmcnt`): first light of this kernel spent
+    // 110 us per tile in a load -> wait -> store -> wait chain.
     if constexpr (MODE == MODE_Z) {
       const int nksS = p.out_f >> 4;
+      int64_t tl[2];
+      bool live[2], blk[2];
+      float f[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int cb = tn * 8 + wn * 2 + ni;
-        if (cb >= p.ncb) continue;
         const int64_t t = (int64_t)cb * 32 + tc;
-        const bool live = t < p.T;
-        const int64_t tl = live ? t : p.T - 1;
-        float f = 1.0f;
-        if (p.rs) f = p.rs[(tl / p.rps) * p.rs_stride];
-        const float* Rrow = p.R + tl * p.out_f;
-        const float* Yrow = p.Y + tl * p.out_f;
-        unsigned char* Srow = p.S + (int64_t)cb * nksS * kRB + tc * 16;
+        blk[ni] = cb < p.ncb;
+        live[ni] = t < p.T;
+        tl[ni] = live[ni] ? t : p.T - 1;
+        f[ni] = p.rs ? p.rs[(tl[ni] / p.rps) * p.rs_stride] : 1.0f;
+      }
+      // the wave's 128 bias values go through a private 512-B LDS slot: reading them back counts on lgkmcnt, so no wait
+      // for a bias value drains the prefetched R / Y loads of the next block
+      float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * 128;
+      if (lane < 32) {
+        f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (4 * WM) + wm * 4) * 32 + lane * 4);
+        *reinterpret_cast<f32x4*>(bias_lds + lane * 4) = bv;
+      }
+      f32x4 r4[2][4], y4[2][4];
+      auto load_block = [&](int bi, int buf) __attribute__((always_inline)) {
+        const int ni = bi >> 2, mi = bi & 3;
+        const int j0 = (tm * (4 * WM) + wm * 4 + mi) * 32;
+        const float* Rrow = p.R + tl[ni] * p.out_f + j0 + 4 * h;
+        const float* Yrow = p.Y + tl[ni] * p.out_f + j0 + 4 * h;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const int j0 = (tm * (4 * WM) + wm * 4 + mi) * 32;
-          f32x4 r4[4], y4[4];
+        for (int g = 0; g < 4; ++g) {
+          r4[buf][g] = *reinterpret_cast<const f32x4*>(Rrow + 8 * g);
+          y4[buf][g] = *reinterpret_cast<const f32x4*>(Yrow + 8 * g);
+        }
+      };
+      load_block(0, 0);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            r4[g] = *reinterpret_cast<const f32x4*>(Rrow + j0 + 8 * g + 4 * h);
-            y4[g] = *reinterpret_cast<const f32x4*>(Yrow + j0 + 8 * g + 4 * h);
+      for (int bi = 0; bi < 8; ++bi) {
+        const int ni = bi >> 2, mi = bi & 3, buf = bi & 1;
+        const int cb = tn * 8 + wn * 2 + ni;
+        const int j0 = (tm * (4 * WM) + wm * 4 + mi) * 32;
+        if (bi + 1 < 8) load_block(bi + 1, buf ^ 1);      // in flight during this block's arithmetic
+        unsigned w[4][3][2];                       // [g][plane][dword]: four bf16 of one plane = weight rows 8g+4h+0..3
+        unsigned bad = 0;                          // elements whose Z needs the cancellation fallback
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + mi * 32 + 8 * g + 4 * h);
+          unsigned pl[4][3];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float a_abs = acc[mi][ni][4 * g + c];
+            const float z = 0.5f * ((y4[buf][g][c] - b4[c]) + a_abs);
+            const bool cancel = !(z > kCancelTol * a_abs);
+            bad |= (cancel ? 1u : 0u) << (4 * g + c);
+            float rr = r4[buf][g][c];
+            if (p.rs) rr = rr * f[ni];
+            float sv = te_sd(rr, z);
+            asm volatile("" : "+v"(sv));            // evaluated for every lane: a select below, not a branch around the division
+            sv = (live[ni] && !cancel) ? sv : 0.0f;
+            split3(sv, pl[c]);
           }
-          unsigned w[4][3][2];                       // [g][plane][dword]: four bf16 of one plane = weight rows 8g+4h+0..3
-          unsigned bad = 0;                          // elements whose Z needs the cancellation fallback
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + j0 + 8 * g + 4 * h);
-            unsigned pl[4][3];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float a_abs = acc[mi][ni][4 * g + c];
-              const float z = 0.5f * ((y4[g][c] - b4[c]) + a_abs);
-              const bool cancel = !(z > kCancelTol * a_abs);
-              bad |= (cancel ? 1u : 0u) << (4 * g + c);
-              float rr = r4[g][c];
-              if (p.rs) rr = rr * f;
-              const float sv = (live && !cancel) ? te_sd(rr, z) : 0.0f;
-              split3(sv, pl[c]);
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              w[g][q][0] = pl[0][q] | (pl[1][q] << 16);
-              w[g][q][1] = pl[2][q] | (pl[3][q] << 16);
-            }
+          for (int q = 0; q < 3; ++q) {
+            w[g][q][0] = pl[0][q] | (pl[1][q] << 16);
+            w[g][q][1] = pl[2][q] | (pl[3][q] << 16);
           }
-          // lanes h = 0 end up with the 16-B pieces g = 0, 1 (8 consecutive features each), lanes h = 1 with g = 2, 3
+        }
+        // lanes h = 0 end up with the 16-B pieces g = 0, 1 (8 consecutive features each), lanes h = 1 with g = 2, 3
 #pragma unroll
-          for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+          for (int q = 0; q < 3; ++q)
 #pragma unroll
-              for (int d = 0; d < 2; ++d) swap_halves(w[g][q][d], w[g + 2][q][d]);
+            for (int d = 0; d < 2; ++d) swap_halves(w[g][q][d], w[g + 2][q][d]);
+        if (blk[ni]) {
+          unsigned char* Srow = p.S + (int64_t)cb * nksS * kRB + tc * 16;
           unsigned char* sp = Srow + (int64_t)((j0 >> 4) + h) * kRB;
 #pragma unroll
           for (int q = 0; q < 3; ++q)
@@ -427,16 +529,17 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
             }
           // rare: (Y - b) and |X||W|^T cancel (nearly every product of the element is negative): the reference's plain
           // positive-part sum, k-ordered, written over the element's three plane values
-          if (!live) bad = 0;
+          if (!live[ni]) bad = 0;
           if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 16-B pieces above are in memory first
+            const float* Rrow = p.R + tl[ni] * p.out_f;
 #pragma clang loop unroll(disable)
             for (int e = 0; e < 16; ++e) {
               if ((bad >> e) & 1u) {
                 const int jj = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
-                const float z = exact_z(p.X + tl * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f);
+                const float z = exact_z(p.X + tl[ni] * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f);
                 float rr = Rrow[jj];
-                if (p.rs) rr = rr * f;
+                if (p.rs) rr = rr * f[ni];
                 unsigned pl[3];
                 split3(te_sd(rr, z), pl);
                 unsigned short* d = reinterpret_cast<unsigned short*>(Srow + (int64_t)(jj >> 4) * kRB + ((jj >> 3) & 1) * 512) + (jj & 7);
@@ -449,29 +552,54 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         }
       }
     } else {
+      f32x4 x4[2][2][4];
+      int64_t tt[2];
+      bool live[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int64_t t = ((int64_t)tn * 8 + wn * 2 + ni) * 32 + tc;
-        if (t >= p.T) continue;
+        live[ni] = t < p.T;
+        tt[ni] = live[ni] ? t : p.T - 1;
 #pragma unroll
         for (int il = 0; il < 2; ++il) {
-          const int i0 = (tm * (2 * WM) + wm * 2 + il) * 32;
+          const float* xr = p.X + tt[ni] * p.in_f + (tm * (2 * WM) + wm * 2 + il) * 32 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) x4[ni][il][g] = *reinterpret_cast<const f32x4*>(xr + 8 * g);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int il = 0; il < 2; ++il) {
+          float* orow = p.out + tt[ni] * p.in_f + (tm * (2 * WM) + wm * 2 + il) * 32 + 4 * h;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int ib = i0 + 8 * g + 4 * h;
-            const f32x4 x4 = *reinterpret_cast<const f32x4*>(p.X + t * p.in_f + ib);
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const float xp = fmaxf(x4[c], 0.0f), xn = fminf(x4[c], 0.0f);
+              const float xv = x4[ni][il][g][c];
+              const float xp = fmaxf(xv, 0.0f), xn = fminf(xv, 0.0f);
               o[c] = 1.0f * (xp * acc[2 * il][ni][4 * g + c] + xn * acc[2 * il + 1][ni][4 * g + c]);
             }
-            *reinterpret_cast<f32x4*>(p.out + t * p.in_f + ib) = o;
+            if (live[ni]) *reinterpret_cast<f32x4*>(orow + 8 * g) = o;
           }
         }
-      }
     }
     __syncthreads();       // every wave is done with the stages before the next fragment's first loads land in them
+    if constexpr (PROF) {
+      if (threadIdx.x == 0) {
+        prof_epi += wall_clock64() - prof_t1;
+        prof_nepi += 1;
+      }
+    }
+  }
+  if constexpr (PROF) {
+    if (threadIdx.x == 0) {
+      long long* o = reinterpret_cast<long long*>(p.flags + 2048) + (size_t)bid * 8;
+      o[0] = prof_loop, o[1] = prof_epi, o[2] = prof_pub, o[3] = prof_wait, o[4] = prof_steps, o[5] = prof_nepi;
+      o[6] = wall_clock64() - prof_start;
+      o[7] = prof_start;
+    }
   }
 }
 
@@ -479,7 +607,7 @@ inline size_t planes_bytes(int64_t rows, int64_t K) {
   return (size_t)te_ceil_div(rows, 32) * 32 * (size_t)K * 6;
 }
 constexpr size_t kPartialBytes = (size_t)512 * 256 * 128 * 4;       // grid x threads x 128 floats, both geometries: 64 MiB
-constexpr size_t kFlagBytes = 4096;                                  // 512 flags + the error word, per pass
+constexpr size_t kFlagBytes = 65536;                                 // 512 flags + the error word (+ study time stamps), per pass
 
 inline int pick_wm(int64_t in_f, int64_t out_f) {
   if (out_f % 256 == 0 && in_f % 128 == 0) return 2;
@@ -487,12 +615,12 @@ inline int pick_wm(int64_t in_f, int64_t out_f) {
   return 0;
 }
 
-template <int WM, int MODE>
+template <int WM, int MODE, int STUDY = 0>
 int launch_x6(const X6Params& p, hipStream_t stream) {
   constexpr int NP = 12 * WM + 24;
-  constexpr int lds = 2 * NP * kFrag;
+  constexpr int lds = 2 * NP * kFrag + 4 * WM * 512;      // two stages + one 512-B bias slot per wave
   static bool configured = false;      // idempotent attribute of the code object (not data-path state)
-  auto kern = x6_kernel<WM, MODE>;
+  auto kern = x6_kernel<WM, MODE, STUDY>;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -583,8 +711,9 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   const unsigned char* wc = wz + te_align_up(planes_bytes(out_f, in_f), 256);
 
   if (phases & TE_X6_PHASE_SPLIT) {
-    hipError_t me = hipMemsetAsync(flag_words, 0, 2 * kFlagBytes, stream);
-    if (me != hipSuccess) return (int)me;
+    // the hand-over flags of both passes start from zero (a kernel, not a memset node: the whole rule stays a chain of
+    // kernel nodes when it is captured in a HIP graph)
+    zero_words_kernel<<<dim3(2 * kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
   }
   if (!x_planes) {
     if (phases & TE_X6_PHASE_SPLIT) {
@@ -595,6 +724,12 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   }
   int wm = pick_wm(in_f, out_f);
   if ((flags & 3) == TE_X6_TILE_128 && wm == 2) wm = 1;      // 128-row weight tiles, two workgroups per CU
+  // few rows: 256-row tiles would leave CUs without a workgroup (the result does not depend on the geometry)
+  if (wm == 2 && te_ceil_div(T, kTileT) * (std::min(in_f, out_f) / 256) < 192) wm = 1;
+#ifdef TE_X6_STUDY
+  const int study = (flags >> 5) & 7;      // study builds: run ablation `study` of the main loop instead
+  flags &= 0x1f;
+#endif
   if ((flags & ~0x1f) != 0 || (flags & 3) == 3) return TE_ERR_INVALID_ARG;
   X6Params p{};
   p.T = T;
@@ -622,6 +757,16 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     p.b_rb_stride = (int64_t)p.nks * kRB;
     p.ntm = (int)(out_f / (128 * wm));
     p.flags = flag_words;
+#ifdef TE_X6_STUDY
+    if (wm == 2 && study == 1) rc = launch_x6<2, MODE_Z, 1>(p, stream);
+    else if (wm == 2 && study == 2) rc = launch_x6<2, MODE_Z, 2>(p, stream);
+    else if (wm == 2 && study == 3) rc = launch_x6<2, MODE_Z, 3>(p, stream);
+    else if (wm == 2 && study == 4) rc = launch_x6<2, MODE_Z, 4>(p, stream);
+    else if (wm == 2 && study == 5) rc = launch_x6<2, MODE_Z, 5>(p, stream);
+    else if (wm == 2 && study == 6) rc = launch_x6<2, MODE_Z, 6>(p, stream);
+    else if (wm == 1 && study == 5) rc = launch_x6<1, MODE_Z, 5>(p, stream);
+    else
+#endif
     rc = (wm == 2) ? launch_x6<2, MODE_Z>(p, stream) : launch_x6<1, MODE_Z>(p, stream);
     if (rc != TE_OK) return rc;
   }
@@ -633,6 +778,16 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     p.b_rb_stride = (int64_t)p.nks * kRB;
     p.ntm = (int)(in_f / (64 * wm));
     p.flags = flag_words + kFlagBytes / 4;
+#ifdef TE_X6_STUDY
+    if (wm == 2 && study == 1) rc = launch_x6<2, MODE_C, 1>(p, stream);
+    else if (wm == 2 && study == 2) rc = launch_x6<2, MODE_C, 2>(p, stream);
+    else if (wm == 2 && study == 3) rc = launch_x6<2, MODE_C, 3>(p, stream);
+    else if (wm == 2 && study == 4) rc = launch_x6<2, MODE_C, 4>(p, stream);
+    else if (wm == 2 && study == 5) rc = launch_x6<2, MODE_C, 5>(p, stream);
+    else if (wm == 2 && study == 6) rc = launch_x6<2, MODE_C, 6>(p, stream);
+    else if (wm == 1 && study == 5) rc = launch_x6<1, MODE_C, 5>(p, stream);
+    else
+#endif
     rc = (wm == 2) ? launch_x6<2, MODE_C>(p, stream) : launch_x6<1, MODE_C>(p, stream);
     if (rc != TE_OK) return rc;
   }
@@ -646,12 +801,15 @@ extern "C" int te_linear_relprop_x6_check(const void* ws, int64_t T, int64_t in_
   if (!ws || !te_linear_relprop_x6_supported(T, in_f, out_f)) return TE_ERR_INVALID_ARG;
   const unsigned char* q = (const unsigned char*)ws + te_align_up(planes_bytes(T, in_f), 256) +
                            te_align_up(planes_bytes(T, out_f), 256) + kPartialBytes;
-  unsigned host[2 * kFlagBytes / 4];
-  hipError_t e = hipMemcpyAsync(host, q, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream_);
+  unsigned host[2][1024];      // the 512 flags + the error word of each pass
+  hipError_t e = hipSuccess;
+  for (int pass = 0; pass < 2 && e == hipSuccess; ++pass)
+    e = hipMemcpyAsync(host[pass], q + pass * kFlagBytes, sizeof(host[pass]), hipMemcpyDeviceToHost, (hipStream_t)stream_);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream_);
   if (e != hipSuccess) return (int)e;
-  // error words sit at index grid (<= 512) of each pass's flag array; any non-zero word after a completed call is an error
-  for (unsigned i = 0; i < 2 * kFlagBytes / 4; ++i)
-    if (host[i]) return 1;
+  // any non-zero word after a completed call is an error (a flag nobody consumed, or the error word)
+  for (int pass = 0; pass < 2; ++pass)
+    for (unsigned i = 0; i < 1024; ++i)
+      if (host[pass][i]) return 1;
   return 0;
 }

@@ -51,21 +51,15 @@ def _attention_gradients(loss, attn_modules):
 
 
 class LRP:
-    """baselines/ViT/ViT_explanation_generator.py:20-41.
+    """baselines/ViT/ViT_explanation_generator.py:20-41.  Batched: B inputs -> B maps (B = 1 is the reference's call).
 
-    ``streams`` (extension, default 1): samples are independent, so a batch can be cut into ``streams`` micro-batches
-    that run forward + backward + relprop each on its own HIP stream.  Kernels of different micro-batches then fill
-    each other's tails (a 12,608-row Linear.relprop pass is 2.3 tile rounds per CU; the third round is a third
-    full), and the small streaming kernels of one overlap the MFMA kernels of the other.  Results are identical to
-    the single-stream path sample by sample; the per-module caches (``get_attn_cam()`` ...) then hold the LAST
-    micro-batch only.  KNOWN ISSUE (round 2): at ViT-B batch 64 on the MI355X, ``streams=2`` stops making progress in
-    its second call (small batches run and are bitwise equal to the serial pass); not diagnosed -- keep the default."""
+    (The round-1 ``streams`` extension -- micro-batches on separate HIP streams -- is gone: it stopped making progress at
+    batch 64 for reasons never diagnosed, and since round 3 the Linear rules run on persistent whole-chip kernels that
+    two streams could only serialise.)"""
 
-    def __init__(self, model, streams=1, overlap_backward=False, prune=False):
+    def __init__(self, model, overlap_backward=False, prune=False):
         self.model = model
         self.model.eval()
-        self.streams = max(1, int(streams))
-        self._side = None
         # (extension) the relprop chain reads only forward caches; the attention gradients are needed by the tail
         # alone.  With overlap_backward the backward pass (main stream) and the relprop rules (side stream) run
         # concurrently and join before the head-mean / rollout tail: the memory-bound backward kernels and the tails
@@ -77,33 +71,7 @@ class LRP:
         self.prune = bool(prune)
 
     def generate_LRP(self, input, index=None, method="transformer_attribution", is_ablation=False, start_layer=0):
-        B = input.shape[0]
-        if self.streams > 1 and input.is_cuda and B >= 2 * self.streams:
-            return self._generate_streamed(input, index, method, is_ablation, start_layer)
         return self._generate(input, index, method, is_ablation, start_layer)
-
-    def _generate_streamed(self, input, index, method, is_ablation, start_layer):
-        B = input.shape[0]
-        if self._side is None or len(self._side) != self.streams:
-            self._side = [torch.cuda.Stream(device=input.device) for _ in range(self.streams)]
-        if index is not None and not torch.is_tensor(index):
-            index = torch.as_tensor(np.asarray(index), device=input.device)
-        main = torch.cuda.current_stream(input.device)
-        bounds = [(B * i) // self.streams for i in range(self.streams + 1)]
-        outs = []
-        for s, lo, hi in zip(self._side, bounds[:-1], bounds[1:]):
-            s.wait_stream(main)
-            with torch.cuda.stream(s):
-                idx = index[lo:hi] if (index is not None and index.numel() == B) else index
-                out = self._generate(input[lo:hi], idx, method, is_ablation, start_layer)
-            outs.append(out)
-        for s, out in zip(self._side, outs):
-            main.wait_stream(s)
-            if out is not None:
-                out.record_stream(main)
-        if outs[0] is None:
-            return None
-        return torch.cat(outs, 0)
 
     def _generate(self, input, index, method, is_ablation, start_layer):
         output = self.model(input)
