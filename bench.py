@@ -98,8 +98,8 @@ def parse_args(argv=None):
                          "fp32-MFMA throughput of the same workload from a second timed run (config.fp32_mfma_*)")
     ap.add_argument("--producers", choices=["stock", "fused"], default="fused",
                     help="fused (default): the attention blocks' forward and attention-gradient backward run on the "
-                         "hand-written producer kernels where the shape qualifies (SURVEY.md 8f.1: head dim 64, N <= 224 "
-                         "-- ViT-B/16 224^2; ViT-L/384 and BERT-512 stay on stock PyTorch); stock: PyTorch-ROCm everywhere")
+                         "hand-written producer kernels (SURVEY.md 8f.1: head dim 64; N <= 224 one workgroup per head, N <= 640 "
+                         "row tiles -- ViT-B/16 224^2, ViT-L/16 384^2 and BERT-512 alike); stock: PyTorch-ROCm everywhere")
     return ap.parse_args(argv)
 
 
@@ -610,8 +610,7 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         idx = CONFIGS[args.config][0]
-        fused_on = args.producers == "fused" and wl.name.startswith("vit") and \
-            ops.attention_forward_supported(wl.tokens, 64)
+        fused_on = args.producers == "fused" and ops.attention_forward_supported(wl.tokens, 64)
         fused_note = "attention blocks on the HIP producer kernels" if fused_on else "stock kernels throughout"
         line = {
             "metric": f"relevance {wl.noun}/sec ({wl.title}, batch {B} per GPU, generate_LRP transformer_attribution)",

@@ -313,6 +313,33 @@ int te_attention_forward_f32(const float* qkv, float* z_qk, float* attn, float* 
 int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn, float* d_qkv,
                               int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk, te_stream_t stream);
 
+/* The same producers for the shapes the one-workgroup-per-head kernels cannot hold (csrc/te_attn_long.hip): head dim 64,
+ * N <= 640 (ViT-L/16 at 384^2: 577, baselines/ViT/ViT_LRP.py:419-425; BERT: 512), q / k / v / out / gradients as
+ * [B,H,N,64] views with element strides (sb, sh, sn) -- the fused 'b n (qkv h d)' activation of ViT or the three separate
+ * 'b n (h d)' activations of BERT (BERT_explainability/modules/BERT/BERT.py:307-365).
+ *   forward : z_qk (optional) = q k^T unscaled ; x = z_qk * scale + mask[b, key] (mask [B,N] additive, NULL = none;
+ *             x_scaled optional: the Add module's first operand, BERT.py:341-342) ; attn = softmax(x) ; out = attn v
+ *   backward: d_attn = d_out v^T ; d_v = attn^T d_out ; need_qk: d_q = d_s k, d_k = d_s^T q with
+ *             d_s = ((d_attn - rowsum(d_attn . attn)) . attn) * scale.  Workspace: B*H*N floats. */
+int te_attention_strided_supported(int64_t N, int64_t D);
+size_t te_attention_backward_strided_workspace_bytes(int64_t B, int64_t H, int64_t N);
+int te_attention_forward_strided_f32(const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                                     const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                     const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                                     const float* mask, float* z_qk, float* x_scaled, float* attn,
+                                     float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                                     int64_t B, int64_t H, int64_t N, int64_t D, float scale, te_stream_t stream);
+int te_attention_backward_strided_f32(const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn,
+                                      const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                                      const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                      const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                                      const float* attn, float* d_attn,
+                                      float* d_q, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,
+                                      float* d_k, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn,
+                                      float* d_v, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                                      int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk,
+                                      void* ws, size_t ws_bytes, te_stream_t stream);
+
 /* The LayerNorm and GELU layers around the Linear rules (modules/layers_ours.py:70-77; ViT_LRP.py:57,184,187,266;
  * BERT.py:18,52,416,463): their relprop rules are the identity, the path needs their forward values (the X / Y the
  * neighbouring rules cache) and their input gradient on the way to the attention maps.

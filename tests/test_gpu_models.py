@@ -735,19 +735,31 @@ def test_config1_vit_b16_batch64(vit_b16, golden_bands):
     torch.cuda.empty_cache()
 
 
-def test_config2_vit_l16_384_batch32():
+@pytest.mark.parametrize("producers", ["stock", "fused"])
+def test_config2_vit_l16_384_batch32(producers):
     """BASELINE.json configs[2]: ViT-L/16 at 384^2 (N = 577, 24 blocks, 1024 wide, 16 heads), batch 32 on one MI355X.
     Size-independent properties at the full size -- finite maps, LRP conservation (token relevance of every sample
     sums to 1), batched == per-sample on the same cache (bitwise) -- plus the CPU oracle on ONE sample's slice of the
     cached tensors (the oracle needs ~10 s per ViT-L sample)."""
     from gpu_util import sliced_relprop_state
-    from transformer_explainability_amd import vit
+    from transformer_explainability_amd import ops, vit
     from transformer_explainability_amd.generators import LRP
     torch.manual_seed(0)
     model = vit.vit_large_patch16_224(img_size=384).eval()
     synthetic_init(model, 0)
     model.to(dev())
     lrp = LRP(model)
+    # producers = fused: attention forward / backward on the row-tile kernels of csrc/te_attn_long.hip (N = 577),
+    # LayerNorm / GELU on te_norm_act.hip -- what bench.py --config vit_l16_384 runs
+    ops.USE_FUSED_PRODUCERS = producers == "fused"
+    try:
+        _config2_body(model, lrp, producers)
+    finally:
+        ops.USE_FUSED_PRODUCERS = False
+
+
+def _config2_body(model, lrp, producers):
+    from gpu_util import sliced_relprop_state
     # probe the footprint at B = 4 before committing to B = 32 (a box driven out of memory is a strike)
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
@@ -757,7 +769,9 @@ def test_config2_vit_l16_384_batch32():
     B = 32
     while B > 4 and not _fits(per_sample * B * 1.15):
         B //= 2
-    record("vit_l16_384.memory", per_sample_gb=per_sample / 2 ** 30, batch=B)
+    record(f"vit_l16_384.{producers}.memory", per_sample_gb=per_sample / 2 ** 30, batch=B)
+    if producers == "fused":
+        assert all(blk.attn._fused_anchor is not None for blk in model.blocks)
     for blk in model.blocks:      # drop the probe's caches before the big batch
         blk.attn.attn = blk.attn.attn_cam = blk.attn.attn_gradients = None
     torch.cuda.empty_cache()
@@ -772,27 +786,38 @@ def test_config2_vit_l16_384_batch32():
         one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
         assert torch.equal(one, maps[i:i + 1])
     ref = O.vit_relprop(oh[i:i + 1].cpu(), cache, num_heads=16, start_layer=1)
-    _assert_map("vit_l16_384.oracle.map_sl1", maps[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)
+    _assert_map(f"vit_l16_384.{producers}.oracle.map_sl1", maps[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)
     # conservation over the whole batch
     cam = model.head.relprop(oh, alpha=1)
     cam = model.pool.relprop(cam.unsqueeze(1), alpha=1)
     for blk in reversed(model.blocks):
         cam = blk.relprop(cam, alpha=1)
     sums = cam.double().sum(dim=(1, 2)).cpu()
-    record("vit_l16_384.conservation", min=float(sums.min()), max=float(sums.max()))
+    record(f"vit_l16_384.{producers}.conservation", min=float(sums.min()), max=float(sums.max()))
     assert (sums - 1.0).abs().max() < 2e-3
 
 
-def test_config3_bert_base_512_batch32():
+@pytest.mark.parametrize("producers", ["stock", "fused"])
+def test_config3_bert_base_512_batch32(producers):
     """BASELINE.json configs[3]: BERT-base, sequence length 512, batch 32, half of the batch padded (last 64 tokens
     masked -> broadcast-mask Add rule).  Finite outputs, conservation, batched == per-sample on the same cache
     (bitwise), oracle on one padded and one unpadded sample."""
-    from gpu_util import sliced_relprop_state
-    from transformer_explainability_amd import bert
-    from transformer_explainability_amd.generators import Generator
+    from transformer_explainability_amd import bert, ops
     model = bert.BertForSequenceClassification(bert.BertConfigLite(num_labels=2)).eval()
     synthetic_init(model, 0)
     model.to(dev())
+    # producers = fused: the self-attention core on csrc/te_attn_long.hip (separate q / k / v, / sqrt(D), padding mask),
+    # LayerNorm / GELU on te_norm_act.hip -- what bench.py --config bert_base_512 runs
+    ops.USE_FUSED_PRODUCERS = producers == "fused"
+    try:
+        _config3_body(model, producers)
+    finally:
+        ops.USE_FUSED_PRODUCERS = False
+
+
+def _config3_body(model, producers):
+    from gpu_util import sliced_relprop_state
+    from transformer_explainability_amd.generators import Generator
     B, N = 32, 512
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(1000, 20000, (B, N), generator=g).to(dev())
@@ -802,10 +827,12 @@ def test_config3_bert_base_512_batch32():
     gen = Generator(model)
     out = gen.generate_LRP(input_ids=ids, attention_mask=mask, start_layer=0).clone()
     assert out.shape == (B, N) and torch.isfinite(out).all()
+    if producers == "fused":
+        assert all(lay.attention.self._fused_anchor is not None for lay in model.bert.encoder.layer)
     oh = _one_hot_of(model.classifier.Y.detach())
     cam = model.relprop(oh, alpha=1)
     sums = cam.double().sum(dim=(1, 2)).cpu()
-    record("bert_base_512.conservation", min=float(sums.min()), max=float(sums.max()))
+    record(f"bert_base_512.{producers}.conservation", min=float(sums.min()), max=float(sums.max()))
     assert (sums - 1.0).abs().max() < 2e-3
     for i in (0, 1):       # padded, unpadded
         with sliced_relprop_state(model, i, B):
@@ -814,7 +841,7 @@ def test_config3_bert_base_512_batch32():
             one = gen.attribution_tail(start_layer=0)
             assert torch.equal(one, out[i:i + 1]), float((one - out[i:i + 1]).abs().max())
         ref = O.bert_relprop(oh[i:i + 1].cpu(), cache, num_heads=12, start_layer=0)
-        _assert_map(f"bert_base_512.oracle.map_sl0.{i}", out[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)
+        _assert_map(f"bert_base_512.{producers}.oracle.map_sl0.{i}", out[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)
 
 
 def test_zz_band_outliers_are_rare():

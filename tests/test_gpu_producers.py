@@ -11,7 +11,9 @@ from oracle.ref_harness import seeded_randn, synthetic_init
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(2, 12, 197), (1, 3, 50), (2, 4, 224), (1, 2, 33), (3, 2, 1), (1, 1, 32), (2, 2, 64)]
+SHAPES = [(2, 12, 197), (1, 3, 50), (2, 4, 224), (1, 2, 33), (3, 2, 1), (1, 1, 32), (2, 2, 64),
+          # beyond 224 tokens: the row-tile kernels of csrc/te_attn_long.hip (ViT-L/16-384: 577; BERT: 512)
+          (1, 2, 577), (2, 3, 512), (1, 2, 225), (1, 1, 640), (1, 2, 300)]
 
 
 def _stock(qkv, H, scale):
@@ -28,7 +30,7 @@ def _stock(qkv, H, scale):
 def test_attention_forward_producer(B, H, N):
     from transformer_explainability_amd import ops
     D = 64
-    assert ops.attention_forward_supported(N, D) and not ops.attention_forward_supported(225, D)
+    assert ops.attention_forward_supported(N, D) and not ops.attention_forward_supported(641, D)
     qkv = rnd((B, N, 3 * H * D), 71).to(dev())
     scale = D ** -0.5
     out, attn, zqk = ops.attention_forward(qkv, H, scale)
@@ -77,8 +79,62 @@ def test_attention_backward_producer(B, H, N, need_qk):
     if need_qk:
         check(f"producer.bwd.d_q({B},{H},{N})", d_qkv[..., :C], qkv.grad[..., :C], 1e-5)
         check(f"producer.bwd.d_k({B},{H},{N})", d_qkv[..., C:2 * C], qkv.grad[..., C:2 * C], 1e-5)
-    else:
-        assert float(d_qkv[..., :2 * C].abs().max()) == 0.0
+    # (need_qk=False: the q / k thirds of d_qkv are scratch -- the block has no consumer for them)
+
+
+@pytest.mark.parametrize("B,H,N,masked", [(2, 12, 512, True), (2, 2, 128, True), (1, 3, 577, False), (3, 2, 40, True),
+                                            (1, 12, 512, False)])
+def test_attention_producer_bert_layout(B, H, N, masked):
+    """The BERT form (BERT.py:336-352): three separate 'b n (h d)' activations, scores / sqrt(D), additive padding mask,
+    softmax, probs v -- forward by-products (unscaled scores, masked scaled scores, probabilities) and all gradients
+    against stock PyTorch on the device; a batch equals its samples bit for bit."""
+    import math
+    from transformer_explainability_amd import ops
+    D = 64
+    C = H * D
+    d = dev()
+    q, k, v = (rnd((B, N, C), 81 + i).to(d).requires_grad_(True) for i in range(3))
+    mask = None
+    if masked:
+        m = torch.ones(B, N)
+        m[::2, N - max(1, N // 8):] = 0
+        mask = ((1.0 - m) * -10000.0).view(B, 1, 1, N).to(d)
+    scale = 1.0 / math.sqrt(D)
+    heads = lambda t: t.view(B, N, H, D).permute(0, 2, 1, 3)      # noqa: E731
+    z = heads(q) @ heads(k).transpose(-1, -2)
+    x = z / math.sqrt(D)
+    if masked:
+        x = x + mask
+    probs = torch.softmax(x, dim=-1)
+    probs.retain_grad()
+    ctx = (probs @ heads(v)).permute(0, 2, 1, 3).reshape(B, N, C)
+    g_out = rnd((B, N, C), 85).to(d)
+    ctx.backward(g_out)
+    out, attn, zqk, xsc = ops.attention_forward_qkv(q.detach(), k.detach(), v.detach(), H, scale, mask=mask, want_z=True,
+                                                    want_x=masked)
+    tag = f"({B},{H},{N},{masked})"
+    check("producer.bert.zqk" + tag, zqk, z, 2e-6)
+    if masked:
+        live = (mask.expand_as(x) == 0)
+        check("producer.bert.x_live" + tag, torch.where(live, xsc, torch.zeros_like(xsc)),
+              torch.where(live, x.detach(), torch.zeros_like(x)), 2e-6)
+        # masked keys: -10000 + score, one fp32 ulp there is 1e-3: the two pipelines' scores differ by rounding
+        assert float((xsc - x.detach()).abs().max()) <= 2e-3
+    check("producer.bert.attn" + tag, attn, probs, 3e-6)
+    check("producer.bert.out" + tag, out, ctx, 3e-6)
+    for need_qk in (True, False):
+        d_q, d_k, d_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        d_attn = ops.attention_backward_qkv(g_out, q.detach(), k.detach(), v.detach(), attn, H, scale,
+                                            d_q if need_qk else None, d_k if need_qk else None, d_v, need_qk=need_qk)
+        check("producer.bert.d_attn" + tag, d_attn, probs.grad, 3e-6)
+        check("producer.bert.d_v" + tag, d_v, v.grad, 3e-6)
+        if need_qk:
+            check("producer.bert.d_q" + tag, d_q, q.grad, 1e-5)
+            check("producer.bert.d_k" + tag, d_k, k.grad, 1e-5)
+    # sample 0 alone == sample 0 of the batch, bitwise
+    one = ops.attention_forward_qkv(q.detach()[:1], k.detach()[:1], v.detach()[:1], H, scale,
+                                    mask=None if mask is None else mask[:1], want_z=True, want_x=masked)
+    assert torch.equal(one[0], out[:1]) and torch.equal(one[1], attn[:1]) and torch.equal(one[2], zqk[:1])
 
 
 @pytest.fixture()

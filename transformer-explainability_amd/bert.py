@@ -36,6 +36,42 @@ def BertConfigLite(**kw):
     return SimpleNamespace(**d)
 
 
+class _FusedSelfAttention(torch.autograd.Function):
+    """the core of BertSelfAttention.forward (BERT.py:336-352: scores, / sqrt(D), + mask, softmax,
+    probs v) on the producer kernels of csrc/te_attn_long.hip instead of ~10 stock launches per direction.
+
+    forward : q, k, v [B,N,C] (the three Linear outputs, read in place as [B,H,N,D] views) -> ctx [B,N,C]; the
+              probabilities, the unscaled scores (matmul1.Y) and the masked scaled scores (add.X[0]) come back as
+              non-differentiable by-products -- the tensors the relprop rules read.
+    backward: d_attn -- the attention gradient the explanation needs -- goes to the module (save_attn_gradients, what
+              the reference's register_hook does, BERT.py:347-348); d_q / d_k / d_v for the layers below unless the
+              module is the lowest one whose gradient is wanted (``_fused_stop_backward``)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, num_heads, scale, module):
+        out, attn, zqk, xsc = ops.attention_forward_qkv(q, k, v, num_heads, scale, mask=mask, want_z=True,
+                                                        want_x=mask is not None)
+        ctx.save_for_backward(q, k, v, attn)
+        ctx.num_heads, ctx.scale, ctx.module = num_heads, scale, module
+        if xsc is None:
+            xsc = zqk.new_empty(0)
+        ctx.mark_non_differentiable(attn, zqk, xsc)
+        return out, attn, zqk, xsc
+
+    @staticmethod
+    def backward(ctx, d_out, _a, _z, _x):
+        q, k, v, attn = ctx.saved_tensors
+        stop = bool(getattr(ctx.module, "_fused_stop_backward", False))
+        d_v = torch.empty_like(v)
+        d_q = None if stop else torch.empty_like(q)
+        d_k = None if stop else torch.empty_like(k)
+        d_attn = ops.attention_backward_qkv(d_out, q, k, v, attn, ctx.num_heads, ctx.scale, d_q, d_k, d_v, need_qk=not stop)
+        ctx.module.save_attn_gradients(d_attn)
+        if stop:
+            return None, None, None, None, None, None, None
+        return d_q, d_k, d_v, None, None, None, None
+
+
 def make_bert_module(L):
     ACT = {"relu": L.ReLU, "tanh": L.Tanh, "gelu": L.GELU}
 
@@ -107,6 +143,12 @@ def make_bert_module(L):
                 raise NotImplementedError("head_mask is off the accelerated path")
             self.head_mask, self.attention_mask = head_mask, attention_mask
             h1, h2, h3 = self.clone(hidden_states, 3)
+            self._fused_anchor = None
+            B, N, _ = hidden_states.shape
+            if (ops.USE_FUSED_PRODUCERS and hidden_states.is_cuda and hidden_states.dtype == torch.float32
+                    and not self.training and ops.attention_forward_supported(N, self.attention_head_size)
+                    and (attention_mask is None or tuple(attention_mask.shape) == (B, 1, 1, N))):
+                return self._forward_fused(h1, h2, h3, attention_mask)
             q = self.transpose_for_scores(self.query(h1))
             k = self.transpose_for_scores(self.key(h2))
             v = self.transpose_for_scores(self.value(h3))
@@ -120,6 +162,27 @@ def make_bert_module(L):
             ctx = self.matmul2([self.dropout(probs), v])
             ctx = ctx.permute(0, 2, 1, 3).contiguous()
             return (ctx.view(*ctx.shape[:-2], self.all_head_size),)
+
+        def _forward_fused(self, h1, h2, h3, attention_mask):
+            """BERT.py:336-352 on the producer kernels.  The rule modules' caches (matmul1.X / .Y, add.X, matmul2.X / .Y)
+            are views of the three Linear outputs and of the kernels' by-products, exactly the tensors the stock
+            forward would have cached there."""
+            B, N, C = h1.shape
+            H, D = self.num_attention_heads, self.attention_head_size
+            ql, kl, vl = self.query(h1), self.key(h2), self.value(h3)
+            ctx, probs, zqk, xsc = _FusedSelfAttention.apply(ql, kl, vl, attention_mask, H, 1.0 / math.sqrt(D), self)
+            self._fused_anchor = ql if ql.requires_grad else None
+            heads = lambda t: t.detach().view(B, N, H, D).permute(0, 2, 1, 3)      # noqa: E731
+            q, k, v = heads(ql), heads(kl), heads(vl)
+            self.save_attn(probs)
+            caches = [(self.matmul1, [q, k.transpose(-1, -2)], zqk), (self.matmul2, [probs, v], heads(ctx))]
+            if attention_mask is not None:
+                caches.append((self.add, [xsc, attention_mask], None))
+            for mod, X, Y in caches:
+                mod.X, mod.Y = X, Y
+                mod._y_version = Y._version if Y is not None else None
+                mod._w_version = (None, None)
+            return (ctx,)
 
         def relprop(self, cam, **kwargs):
             """BERT.py:367-409.  cam [B,N,C] -> relevance of hidden_states [B,N,C]."""

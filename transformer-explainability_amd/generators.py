@@ -44,6 +44,10 @@ def _attention_gradients(loss, attn_modules):
         finally:
             lowest._fused_stop_backward = False
         return
+    if any(a is not None for a in anchors):
+        raise ops._lib.TeError("attention gradients: some of the listed blocks ran on the producer kernels and some on "
+                               "stock PyTorch (a frozen qkv layer, or a block in train mode?); the gradient driver "
+                               "handles one kind per pass -- set ops.USE_FUSED_PRODUCERS = False for this model")
     attns = [m.get_attn() for m in attn_modules]
     grads = torch.autograd.grad(loss, attns, retain_graph=False, allow_unused=False)
     for m, g in zip(attn_modules, grads):

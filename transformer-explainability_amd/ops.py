@@ -327,7 +327,64 @@ USE_FUSED_PRODUCERS = False
 
 
 def attention_forward_supported(N: int, D: int) -> bool:
-    return bool(_lib.load().te_attention_forward_supported(int(N), int(D)))
+    """One of the producer kernel families takes the shape: the one-workgroup-per-head kernels (N <= 224) or the
+    row-tile kernels of csrc/te_attn_long.hip (N <= 640)."""
+    lib = _lib.load()
+    return bool(lib.te_attention_forward_supported(int(N), int(D)) or lib.te_attention_strided_supported(int(N), int(D)))
+
+
+def _heads(t: Tensor, H: int):
+    """[B,N,H*64] activation (any batch / token strides, contiguous features) -> (pointer tensor, sb, sh, sn) of its
+    [B,H,N,64] view."""
+    sb, sn, sc = t.stride()
+    if sc != 1:
+        raise _lib.TeError("attention producers need a contiguous feature dimension")
+    return t, sb, 64, sn
+
+
+def attention_forward_qkv(q: Tensor, k: Tensor, v: Tensor, num_heads: int, scale: float,
+                          mask: Optional[Tensor] = None, want_z: bool = True, want_x: bool = False):
+    """q, k, v: [B,N,C] views ('b n (h d)', e.g. thirds of the fused ViT activation or BERT's three Linear outputs);
+    mask [B,N] additive or None -> (out [B,N,C], attn [B,H,N,N], z_qk [B,H,N,N] unscaled or None, x = z_qk * scale + mask
+    [B,H,N,N] or None).  csrc/te_attn_long.hip."""
+    B, N, C = q.shape
+    H, D = num_heads, C // num_heads
+    dev = q.device
+    out = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    attn = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
+    zqk = torch.empty((B, H, N, N), dtype=torch.float32, device=dev) if want_z else None
+    xsc = torch.empty((B, H, N, N), dtype=torch.float32, device=dev) if want_x else None
+    mk = None if mask is None else _c(mask.reshape(B, N))
+    (q, qb, qh, qn), (k, kb, kh, kn), (v, vb, vh, vn) = _heads(_prep(q), H), _heads(_prep(k), H), _heads(_prep(v), H)
+    with _on_device(q) as lib, _timed("attention_forward", 4.0 * B * H * N * N * D,
+                                      4.0 * B * ((2 + bool(want_x)) * H * N * N + 4 * N * C)):
+        _lib.check(lib.te_attention_forward_strided_f32(_ptr(q), qb, qh, qn, _ptr(k), kb, kh, kn, _ptr(v), vb, vh, vn,
+                                                        _ptr(mk), _ptr(zqk), _ptr(xsc), _ptr(attn), _ptr(out), N * C, 64, C,
+                                                        B, H, N, D, float(scale), _stream(q)),
+                   "te_attention_forward_strided_f32")
+    return out, attn, zqk, xsc
+
+
+def attention_backward_qkv(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, attn: Tensor, num_heads: int, scale: float,
+                           d_q: Optional[Tensor], d_k: Optional[Tensor], d_v: Tensor, need_qk: bool = True) -> Tensor:
+    """Gradient of attention_forward_qkv: d_out [B,N,C]; d_q / d_k / d_v: [B,N,C] views written in place (d_q, d_k may be
+    None with need_qk=False).  Returns d_attn [B,H,N,N]."""
+    B, N, C = d_out.shape
+    H, D = num_heads, C // num_heads
+    d_out, attn = _c(d_out), _c(attn)
+    d_attn = torch.empty_like(attn)
+    hd = lambda t: (None, 0, 0, 0) if t is None else _heads(_prep(t), H)      # noqa: E731
+    (q, qb, qh, qn), (k, kb, kh, kn), (v, vb, vh, vn) = hd(q), hd(k), hd(v)
+    (dq, dqb, dqh, dqn), (dk, dkb, dkh, dkn), (dv, dvb, dvh, dvn) = hd(d_q), hd(d_k), hd(d_v)
+    with _on_device(d_out) as lib, _timed("attention_backward", (8.0 if need_qk else 4.0) * B * H * N * N * D,
+                                          4.0 * B * ((4 if need_qk else 2) * H * N * N + 8 * N * C)):
+        ws = _ws(lib.te_attention_backward_strided_workspace_bytes(B, H, N), d_out)
+        _lib.check(lib.te_attention_backward_strided_f32(_ptr(d_out), N * C, 64, C, _ptr(q), qb, qh, qn, _ptr(k), kb, kh, kn,
+                                                         _ptr(v), vb, vh, vn, _ptr(attn), _ptr(d_attn), _ptr(dq), dqb, dqh,
+                                                         dqn, _ptr(dk), dkb, dkh, dkn, _ptr(dv), dvb, dvh, dvn, B, H, N, D,
+                                                         float(scale), int(bool(need_qk)), _ptr(ws), ws.numel(),
+                                                         _stream(d_out)), "te_attention_backward_strided_f32")
+    return d_attn
 
 
 def attention_forward(qkv: Tensor, num_heads: int, scale: float) -> Tuple[Tensor, Tensor, Tensor]:
@@ -337,6 +394,9 @@ def attention_forward(qkv: Tensor, num_heads: int, scale: float) -> Tuple[Tensor
     B, N, C3 = qkv.shape
     C = C3 // 3
     H, D = num_heads, C // num_heads
+    if not _lib.load().te_attention_forward_supported(N, D):
+        out, attn, zqk, _ = attention_forward_qkv(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], num_heads, scale)
+        return out, attn, zqk
     out = torch.empty((B, N, C), dtype=torch.float32, device=qkv.device)
     attn = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
     zqk = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
@@ -347,15 +407,20 @@ def attention_forward(qkv: Tensor, num_heads: int, scale: float) -> Tuple[Tensor
 
 
 def attention_backward(d_out: Tensor, qkv: Tensor, attn: Tensor, num_heads: int, scale: float,
-                       need_qk: bool = True) -> Tuple[Tensor, Tensor]:
-    """Gradient of attention_forward: d_out [B,N,C] -> (d_attn [B,H,N,N], d_qkv [B,N,3C]).  need_qk=False leaves the
-    q / k thirds of d_qkv zero (nothing below consumes them)."""
+                       need_qk: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """Gradient of attention_forward: d_out [B,N,C] -> (d_attn [B,H,N,N], d_qkv [B,N,3C]).  need_qk=False: nothing below
+    consumes d_qkv (the lowest block whose attention gradient is wanted): only d_attn is meaningful, d_qkv is scratch."""
     d_out, qkv, attn = _c(d_out), _c(qkv), _c(attn)
     B, N, C3 = qkv.shape
     C = C3 // 3
     H, D = num_heads, C // num_heads
+    d_qkv = torch.empty_like(qkv)
+    if not _lib.load().te_attention_forward_supported(N, D):
+        th = lambda t, i: t[..., i * C:(i + 1) * C]      # noqa: E731
+        d_attn = attention_backward_qkv(d_out, th(qkv, 0), th(qkv, 1), th(qkv, 2), attn, num_heads, scale,
+                                        th(d_qkv, 0), th(d_qkv, 1), th(d_qkv, 2), need_qk=need_qk)
+        return d_attn, d_qkv
     d_attn = torch.empty_like(attn)
-    d_qkv = torch.empty_like(qkv) if need_qk else torch.zeros_like(qkv)
     with _on_device(qkv) as lib, _timed("attention_backward", (8.0 if need_qk else 4.0) * B * H * N * N * D,
                                         4.0 * B * ((4 if need_qk else 2) * H * N * N + 8 * N * C)):
         _lib.check(lib.te_attention_backward_f32(_ptr(d_out), _ptr(qkv), _ptr(attn), _ptr(d_attn), _ptr(d_qkv), B, H, N,
