@@ -87,8 +87,10 @@ def parse_args(argv=None):
     ap.add_argument("--prune", choices=["on", "off"], default="off",
                     help="skip the relprop rules and attention gradients of the blocks below --start-layer (their "
                          "attn_cam never reaches the map); off = every block, as the reference does")
-    ap.add_argument("--overlap-backward", choices=["on", "off"], default="off",
-                    help="run the relprop rules on a side stream beside the attention-gradient backward pass")
+    ap.add_argument("--overlap-backward", choices=["on", "off"], default="on",
+                    help="run the relprop rules on a side stream beside the attention-gradient backward pass (default on "
+                         "since round 3: bitwise-equal maps, graph-capturable, +2.5 % -- 773.6 vs 754.8 maps/s; the "
+                         "eager probe step that feeds the roofline block always runs serially)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="consecutive steps (batches) in flight, each on its own HIP stream (eager launches)")
     ap.add_argument("--linear", choices=["x6", "fp32"], default="x6",
@@ -184,7 +186,7 @@ class KernelTimer:
 def mfma_peak(name):
     """The MFMA roof a kernel group is priced against: the x6 kernels execute bf16 MFMAs (their flops are the EXECUTED
     bf16 work, six partial products per fp32 product), everything else fp32 MFMAs."""
-    return MFMA_BF16_PEAK_TFLOPS if name.startswith("linear_x6") else MFMA_F32_PEAK_TFLOPS
+    return MFMA_BF16_PEAK_TFLOPS if "x6" in name else MFMA_F32_PEAK_TFLOPS
 
 
 KERNEL_GROUPS = {
@@ -193,7 +195,10 @@ KERNEL_GROUPS = {
                                                 "products of 2*T*in*out flops), layers_ours.py:220-225"),
     "linear_x6_zpass": ("x6_kernel<2, MODE_Z>", "Linear.relprop Z-pass from the forward output on bf16 MFMAs (6 products), "
                                                 "S written as bf16 planes, layers_ours.py:216-219"),
-    "linear_x6_split": ("memset + split_kernel<OP_ABS>", "|X| -> three bf16 planes in MFMA-fragment order"),
+    "linear_x6_split": ("zero_words_kernel + split_kernel<OP_ABS>", "|X| -> three bf16 planes in MFMA-fragment order"),
+    "linear_forward_x6": ("split_kernel<OP_ID> + x6_kernel<2, MODE_G>", "producer: y = x W^T + b (nn.Linear, "
+                          "layers_ours.py:207) on bf16 MFMAs, 6 products of 2*T*in*out flops"),
+    "linear_backward_x6": ("split_kernel<OP_ID> + x6_kernel<2, MODE_G>", "producer: d_x = d_y W on bf16 MFMAs"),
     "linear_cpass": ("linear_k2_kernel<0,false,false>", "Linear.relprop C-pass, layers_ours.py:220-225"),
     "linear_zpass_fwd": ("linear_k1_kernel<ZM_FWD>", "Linear.relprop Z-pass from the forward output, layers_ours.py:216-219"),
     "linear_zpass": ("linear_k1_kernel<ZM_OURS>", "Linear.relprop Z-pass (two products), layers_ours.py:216-219"),
@@ -238,7 +243,7 @@ def kernel_table(timer):
                "algorithmic_flops_per_launch": s["flops_per_launch"], "algorithmic_bytes_per_launch": s["bytes_per_launch"],
                "achieved": round(s["tflops"] if bound == "mfma" else s["tbs"], 4),
                "peak": mfma_peak(name) if bound == "mfma" else HBM_PEAK_TBS,
-               "mfma_dtype": ("bf16 (executed flops)" if name.startswith("linear_x6") else "f32") if bound == "mfma" else None,
+               "mfma_dtype": ("bf16 (executed flops)" if "x6" in name else "f32") if bound == "mfma" else None,
                "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": round(max(t_f, t_b) / t, 4)}
         out.append(row)
     out.sort(key=lambda r: -r["avg_us"] * r["launches"])
@@ -504,19 +509,29 @@ def main():
     if not args.no_roofline:
         ops.KERNEL_TIMER = timer
 
+    if args.inflight > 1 and not os.environ.get("TE_ALLOW_INFLIGHT"):
+        # Measured in round 3: two step graphs replayed concurrently on two streams stop making progress on this ROCm
+        # build (every run with --inflight 2 / 3 ran into its 300 s limit; not diagnosed: each attempt costs minutes of
+        # GPU time).  Refuse instead of hanging the box.
+        sys.exit("bench.py: --inflight > 1 is disabled (concurrent step graphs hang, see DESIGN.md section 7); "
+                 "set TE_ALLOW_INFLIGHT=1 to try it anyway")
     lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
 
     # The graph is captured BEFORE the process group exists: RCCL's proxy / watchdog threads touch the HIP runtime on
     # their own and must never meet an open capture; replay afterwards is an ordinary launch.
     graphed = None
+    lane_graphs = None           # --inflight N with graphs: one captured step (own static buffers) per lane
     use_graph = args.graph == "on" or (args.graph == "auto" and args.config == "vit_b16_224")
-    if use_graph and args.inflight == 1:
+    if use_graph:
         try:
-            graphed = GraphedCall(wl.eager, wl.inputs)
-            log("HIP graph of one step captured")
+            if args.inflight == 1:
+                graphed = GraphedCall(wl.eager, wl.inputs)
+            else:
+                lane_graphs = [GraphedCall(wl.eager, wl.inputs) for _ in range(args.inflight)]
+            log(f"HIP graph of one step captured (x{max(1, args.inflight)})")
         except Exception as exc:      # capture is an optimisation of the host side only: fall back to eager launches
-            graphed = None
+            graphed = lane_graphs = None
             torch.cuda.synchronize()
             log(f"HIP graph capture failed ({type(exc).__name__}: {exc}); running eagerly")
 
@@ -529,14 +544,18 @@ def main():
         if graphed is not None and not eager:
             return graphed(*wl.inputs)
         if eager:
+            join()                       # the probe step runs alone: its kernel durations must be its own
             return wl.eager_serial(*wl.inputs)
         if lanes is None:
             return wl.eager(*wl.inputs)
         # every tensor of a step is allocated, produced and consumed on that step's stream
-        lane = lanes[counter[0] % len(lanes)]
+        i = counter[0] % len(lanes)
+        lane = lanes[i]
         counter[0] += 1
         lane.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(lane):
+            if lane_graphs is not None:
+                return lane_graphs[i](*wl.inputs)
             return wl.eager(*wl.inputs)
 
     def join():
@@ -556,9 +575,10 @@ def main():
     for k in range(args.steps):
         # with graph replay, ONE step of the timed region runs eagerly with a HIP-event pair around every C-ABI call of
         # the relprop path (events cannot be recorded inside a replayed graph); same kernels, same order, one stream
-        probe = (graphed is None) or (k == args.steps - 1)
+        any_graph = graphed is not None or lane_graphs is not None
+        probe = (not any_graph and lanes is None) or (k == args.steps - 1)
         timer.enabled = probe and not args.no_roofline
-        maps = step(eager=probe and graphed is not None and not args.no_roofline)
+        maps = step(eager=probe and (any_graph or lanes is not None) and not args.no_roofline)
     host_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (GPU still running)
     join()
     gathered = parallel.gather_maps(maps, world * B)
@@ -581,8 +601,9 @@ def main():
     # Rounds stay comparable: with the x6 Linear rules the same workload is timed once more on the fp32-MFMA kernels of
     # csrc/te_linear.hip (own graph capture, one warm-up, the same number of steps); N = 1 only, after the timed region.
     fp32_cmp = {}
-    used_graph = graphed is not None
-    if args.linear == "x6" and world == 1 and args.inflight == 1:
+    used_graph = graphed is not None or lane_graphs is not None
+    if args.linear == "x6" and world == 1:
+        lane_graphs = None
         ops.USE_LINEAR_X6 = False
         try:
             g2 = None
@@ -600,8 +621,8 @@ def main():
             assert torch.isfinite(m2).all()
             fp32_cmp = {"fp32_mfma_maps_per_s" if wl.noun == "maps" else "fp32_mfma_sequences_per_s": B * args.steps / e2,
                         "fp32_mfma_ms_per_step": e2 / args.steps * 1e3,
-                        "fp32_mfma_note": "the same step with the Linear rules on the fp32-MFMA kernels (te_linear.hip); "
-                                          "second timed run of this process"}
+                        "fp32_mfma_note": "the same step with the Linear rules on the fp32-MFMA kernels (te_linear.hip), one "
+                                          "graph replayed step after step; second timed run of this process"}
             log(f"fp32-MFMA comparison run: {e2 / args.steps * 1e3:.2f} ms/step")
             del g2
         finally:

@@ -297,6 +297,18 @@ int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_sca
                              te_stream_t stream);
 int te_linear_relprop_x6_check(const void* ws, int64_t T, int64_t in_f, int64_t out_f, te_stream_t stream);
 
+/* The plain fp32 product on the same kernels (the forward output and the input gradient of a Linear layer,
+ * modules/layers_ours.py:207 = nn.Linear): out [T, M] = X [T, K] . W^T + bias [M] with W given as signed P3 planes of an
+ * [M, K] matrix.  te_linear_x6_split_matrix_f32 builds such planes from a row-major [rows, K] matrix (transposed = 0) or
+ * from its transpose stored as [K, rows] (transposed = 1: the planes of W^T for d_x = d_y W).  M % 128 == 0, K % 16 == 0.
+ * x_planes = NULL: X is split into the workspace first. */
+int te_gemm_x6_supported(int64_t T, int64_t K, int64_t M);
+size_t te_gemm_x6_workspace_bytes(int64_t T, int64_t K, int64_t M);
+int te_linear_x6_split_matrix_f32(const float* A, int64_t rows, int64_t K, int transposed, void* planes,
+                                  size_t planes_bytes, te_stream_t stream);
+int te_gemm_x6_f32(const float* X, const void* x_planes, const void* w_planes, const float* bias, float* out,
+                   int64_t T, int64_t K, int64_t M, void* ws, size_t ws_bytes, te_stream_t stream);
+
 /* ---- producers of the cached tensors ----------------------------------------------------
  * The attention block of baselines/ViT/ViT_LRP.py:132-152 (and its gradient, the tensor save_attn_gradients receives,
  * :144-145) on the fused qkv activation [B,N,3*H*D] ('b n (qkv h d)'), head dim 64, N <= 224 (k and v of a head stay

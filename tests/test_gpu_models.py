@@ -714,8 +714,10 @@ def test_config1_vit_b16_batch64(vit_b16, golden_bands):
         keys = [f"vit_b16.seed1x64.img{i}.sl1" for i in (31, 63)]
         _assert_within_band("vit_b16_b64.golden.map_sl1", maps[[31, 63]],
                             torch.cat([golden_bands[k + ".map"] for k in keys], 0), golden_bands, keys)
-        # the graph-replayed step (what bench.py times) == the eager step, bitwise; also on a second batch
-        g = GraphedCall(lambda t: lrp.generate_LRP(t, method="transformer_attribution", start_layer=1), (x,))
+        # the graph-replayed step (what bench.py times: relprop on a side stream beside the backward pass) == the serial
+        # eager step, bitwise; also on a second batch
+        lrp_ov = LRP(model, overlap_backward=True)
+        g = GraphedCall(lambda t: lrp_ov.generate_LRP(t, method="transformer_attribution", start_layer=1), (x,))
         assert torch.equal(g(x), maps)
         x2 = seeded_randn((B, 3, 224, 224), 9).to(dev())
         rep = g(x2).clone()

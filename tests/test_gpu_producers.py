@@ -137,6 +137,60 @@ def test_attention_producer_bert_layout(B, H, N, masked):
     assert torch.equal(one[0], out[:1]) and torch.equal(one[1], attn[:1]) and torch.equal(one[2], zqk[:1])
 
 
+@pytest.mark.parametrize("T,K,M", [(788, 768, 2304), (1576, 3072, 768), (600, 1024, 4096), (300, 128, 384), (12608, 768, 768)])
+def test_linear_producer_x6_gemm(T, K, M):
+    """SURVEY.md 8f.1, the Linear layers themselves: y = x W^T + b and d_x = d_y W on the split-operand bf16 kernels
+    (te_gemm_x6_f32) against stock PyTorch on the device and against fp64: fp32-class accuracy (no worse than rocBLAS's
+    fp32 GEMM), rows independent of the batch (bitwise), weight planes cached per weight version."""
+    from transformer_explainability_amd import ops
+    d = dev()
+    x, W, b = rnd((T, K), 91).to(d), rnd((M, K), 92, 0.05).to(d), rnd((M,), 93, 0.3).to(d)
+    dy = rnd((T, M), 94).to(d)
+    assert ops.gemm_x6_supported(T, K, M)
+    cache = {}
+    y = ops.gemm_x6(x, ops.x6_matrix_planes(W, False, cache), b, M)
+    ys = torch.nn.functional.linear(x, W, b)
+    check(f"producer.linear.y({T},{K},{M})", y, ys, 4e-6)      # (two fp32-class roundings; 2.9e-6 at K = 3072)
+    y64 = torch.nn.functional.linear(x.double().cpu(), W.double().cpu(), b.double().cpu())
+    e6, es = float((y.cpu().double() - y64).pow(2).mean().sqrt()), float((ys.cpu().double() - y64).pow(2).mean().sqrt())
+    record(f"producer.linear.fp64({T},{K},{M})", x6_rms=e6, stock_rms=es)
+    assert e6 <= 1.1 * es + 1e-9, (e6, es)
+    if ops.gemm_x6_supported(T, M, K):
+        dx = ops.gemm_x6(dy, ops.x6_matrix_planes(W, True, cache), None, K)
+        check(f"producer.linear.dx({T},{K},{M})", dx, dy @ W, 4e-6)      # (two fp32-class roundings, K up to 4096)
+        assert "x6_gemm_planes_T" in cache
+    assert "x6_gemm_planes" in cache
+    h = T // 2
+    assert torch.equal(ops.gemm_x6(x[:h].contiguous(), ops.x6_matrix_planes(W, False, cache), b, M), y[:h])
+    assert torch.equal(ops.gemm_x6(x[7:300].contiguous(), ops.x6_matrix_planes(W, False, cache), b, M), y[7:300])
+
+
+def test_linear_layer_on_producers():
+    """rules.Linear.forward / backward through autograd with ops.USE_FUSED_PRODUCERS: same values and input gradient as the
+    stock layer to fp32 rounding; the stock path below 256 rows and for shapes the kernels do not tile."""
+    from transformer_explainability_amd import ops, rules
+    d = dev()
+    lin = rules.Linear(768, 3072).to(d).eval()
+    x = rnd((4, 197, 768), 95).to(d).requires_grad_(True)
+    g = rnd((4, 197, 3072), 96).to(d)
+    y0 = lin(x)
+    (dx0,) = torch.autograd.grad(y0, x, g)
+    was = ops.USE_X6_GEMM
+    ops.USE_FUSED_PRODUCERS = ops.USE_X6_GEMM = True
+    try:
+        y1 = lin(x)
+        assert "x6_gemm_planes" in rules.x6_cache(lin)
+        (dx1,) = torch.autograd.grad(y1, x, g)
+        check("producer.linear.layer.y", y1, y0, 2e-6)
+        check("producer.linear.layer.dx", dx1, dx0, 2e-6)
+        assert lin.Y is y1 and lin.X.shape == x.shape
+        small = lin(x[:1])                       # 197 rows: stock kernels
+        assert torch.equal(small, torch.nn.functional.linear(x[:1], lin.weight, lin.bias))
+    finally:
+        ops.USE_FUSED_PRODUCERS = False
+        ops.USE_X6_GEMM = was
+
+
 @pytest.fixture()
 def fused():
     from transformer_explainability_amd import ops

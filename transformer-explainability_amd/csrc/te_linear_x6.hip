@@ -50,27 +50,35 @@ constexpr int kMinFrag = 4;                   // a cut closer than this many K-s
 constexpr float kCancelTol = 0.0078125f;      // as te_linear.hip
 constexpr unsigned kSpinLimit = 1u << 22;     // bounded wait for a predecessor's accumulators (~1 s): never hang the GPU
 
-enum { MODE_Z = 0, MODE_C = 1 };
+enum { MODE_Z = 0, MODE_C = 1, MODE_G = 2 };      // Z-pass, C-pass, plain GEMM out = B A^T + bias
 
 #define TE_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ unsigned bf16_rn(float x) {      // round to nearest even, finite input
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf16_f32(unsigned b) { return __uint_as_float(b << 16); }
-// x = p[0] + p[1] + p[2] exactly (the residual of a round-to-nearest bf16 is representable in fp32)
-__device__ __forceinline__ void split3(float x, unsigned (&p)[3]) {
+// x = p[0] + p[1] + p[2] exactly: round to nearest even (v_cvt_pk_bf16_f32), subtract (the residual of a round-to-nearest
+// bf16 is representable in fp32), repeat.  Pairs: p[q] = the packed bf16 pair (x0 low half, x1 high half) of plane q.
+__device__ __forceinline__ void split3_pk(float x0, float x1, unsigned (&p)[3]) {
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    p[q] = bf16_rn(x);
-    x = x - bf16_f32(p[q]);
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+    p[q] = u;
+    x0 = x0 - __uint_as_float(u << 16);
+    x1 = x1 - __uint_as_float(u & 0xffff0000u);
   }
 }
+__device__ __forceinline__ void split3(float x, unsigned (&p)[3]) {
+  unsigned pk[3];
+  split3_pk(x, 0.0f, pk);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) p[q] = pk[q] & 0xffffu;
+}
 
-enum { OP_ABS = 0, OP_POS = 1, OP_NEG = 2 };
+enum { OP_ABS = 0, OP_POS = 1, OP_NEG = 2, OP_ID = 3 };
 template <int OP>
 __device__ __forceinline__ float apply_op(float x) {
+  if constexpr (OP == OP_ID) return x;
   if constexpr (OP == OP_ABS) return __int_as_float(__float_as_int(x) & 0x7fffffff);
   const int b = __float_as_int(x);
   if constexpr (OP == OP_POS) return __int_as_float(b > 0 ? b : 0);
@@ -110,9 +118,9 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = 0.0f;
   }
-  unsigned p[16][3];
+  unsigned p[8][3];                    // [pair of consecutive k][plane]
 #pragma unroll
-  for (int e = 0; e < 16; ++e) split3(apply_op<OP>(v[e]), p[e]);
+  for (int e = 0; e < 8; ++e) split3_pk(apply_op<OP>(v[2 * e]), apply_op<OP>(v[2 * e + 1]), p[e]);
   unsigned char* d = dst + ((rb * nks + ks) * group + sign * 3) * kFrag + r * 16;
 #pragma unroll
   for (int q = 0; q < 3; ++q)
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
     for (int kh = 0; kh < 2; ++kh) {
       u32x4 w;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = p[8 * kh + 2 * e][q] | (p[8 * kh + 2 * e + 1][q] << 16);
+      for (int e = 0; e < 4; ++e) w[e] = p[4 * kh + e][q];
       *reinterpret_cast<u32x4*>(d + q * kFrag + kh * 512) = w;
     }
 }
@@ -186,7 +194,7 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_keep, unsigned& hi_keep
 template <int WM, int MODE, int STUDY = 0>
 __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
   constexpr int NW = 4 * WM;                         // waves
-  constexpr int G = (MODE == MODE_Z) ? 3 : 6;        // pieces of one A group (32 rows [x 2 signs]) per K16 step
+  constexpr int G = (MODE == MODE_C) ? 6 : 3;        // pieces of one A group (32 rows [x 2 signs]) per K16 step
   constexpr int NPA = 12 * WM, NPB = 24;             // 1-KiB pieces of one stage: weight side, activation side
   constexpr int NP = NPA + NPB;
   constexpr int PBW = NPB / 3 / NW;                  // activation-side 32-row blocks each wave stages (2 or 1)
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     // ---- what this wave stages per step: the three planes of ONE weight-side 32-row block [one sign] and of PBW
     //      activation-side blocks -- each 3 KiB contiguous in memory and in the stage; wave-uniform pointers ----
     const unsigned char* srcA;
-    if constexpr (MODE == MODE_Z)
+    if constexpr (MODE != MODE_C)
       srcA = p.A + (int64_t)(tm * GROUPS + wave) * p.a_group_stride + (int64_t)k0 * kRB;
     else
       srcA = p.A + (int64_t)(tm * GROUPS + (wave >> 1)) * p.a_group_stride + (int64_t)k0 * (2 * kRB) + (wave & 1) * kRB;
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + mi * 32 + 8 * g + 4 * h);
-          unsigned pl[4][3];
+          float sv4[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const float a_abs = acc[mi][ni][4 * g + c];
@@ -499,13 +507,15 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
             if (p.rs) rr = rr * f[ni];
             float sv = te_sd(rr, z);
             asm volatile("" : "+v"(sv));            // evaluated for every lane: a select below, not a branch around the division
-            sv = (live[ni] && !cancel) ? sv : 0.0f;
-            split3(sv, pl[c]);
+            sv4[c] = (live[ni] && !cancel) ? sv : 0.0f;
           }
+          unsigned lo[3], hi[3];
+          split3_pk(sv4[0], sv4[1], lo);
+          split3_pk(sv4[2], sv4[3], hi);
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
-            w[g][q][0] = pl[0][q] | (pl[1][q] << 16);
-            w[g][q][1] = pl[2][q] | (pl[3][q] << 16);
+            w[g][q][0] = lo[q];
+            w[g][q][1] = hi[q];
           }
         }
         // lanes h = 0 end up with the 16-B pieces g = 0, 1 (8 consecutive features each), lanes h = 1 with g = 2, 3
@@ -550,6 +560,29 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
             }
           }
         }
+      }
+    } else if constexpr (MODE == MODE_G) {
+      // plain product: out[t][m] = acc + bias[m] (fp32 row-major [T, M]); the wave's 128 bias values through its LDS slot
+      float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * 128;
+      if (lane < 32) {
+        f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (4 * WM) + wm * 4) * 32 + lane * 4);
+        *reinterpret_cast<f32x4*>(bias_lds + lane * 4) = bv;
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int64_t t = ((int64_t)tn * 8 + wn * 2 + ni) * 32 + tc;
+        float* orow = p.out + (t < p.T ? t : 0) * p.out_f + (tm * (4 * WM) + wm * 4) * 32 + 4 * h;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + mi * 32 + 8 * g + 4 * h);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = acc[mi][ni][4 * g + c] + b4[c];
+            if (t < p.T) *reinterpret_cast<f32x4*>(orow + mi * 32 + 8 * g) = o;
+          }
       }
     } else {
       f32x4 x4[2][2][4];
@@ -675,6 +708,78 @@ extern "C" int te_linear_x6_split_abs_f32(const float* X, int64_t rows, int64_t 
   if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes)) return TE_ERR_WORKSPACE;
   split_kernel<OP_ABS, false><<<dim3((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8)), dim3(256), 0,
                                 (hipStream_t)stream_>>>(X, (unsigned char*)planes, rows, K, 3, 0);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// ---- plain GEMM on the same machinery (the forward / input-gradient products of a Linear layer) -------
+// out [T, M] = X [T, K] . Wp^T + bias [M], Wp = signed P3 planes of an [M, K] matrix (te_linear_x6_split_matrix_f32: of W
+// itself for the forward product, of W^T for the input gradient d_x = d_y W).
+extern "C" int te_gemm_x6_supported(int64_t T, int64_t K, int64_t M) {
+  return (T >= 1 && K >= 128 && M >= 128 && K % 16 == 0 && M % 128 == 0 && K <= (1 << 20) && M <= (1 << 20) &&
+          T <= (int64_t)1 << 26) ? 1 : 0;
+}
+
+extern "C" int te_linear_x6_split_matrix_f32(const float* A, int64_t rows, int64_t K, int transposed, void* planes,
+                                             size_t planes_bytes_, te_stream_t stream_) {
+  if (!A || !planes || rows < 1) return TE_ERR_INVALID_ARG;
+  if (K < 16 || K % 16 || !te_aligned16(A) || rows > ((int64_t)1 << 26)) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes)) return TE_ERR_WORKSPACE;
+  const dim3 grid((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8));
+  if (transposed)       // A is [K, rows] in memory
+    split_kernel<OP_ID, true><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(A, (unsigned char*)planes, rows, K, 3, 0);
+  else
+    split_kernel<OP_ID, false><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(A, (unsigned char*)planes, rows, K, 3, 0);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+extern "C" size_t te_gemm_x6_workspace_bytes(int64_t T, int64_t K, int64_t M) {
+  if (!te_gemm_x6_supported(T, K, M)) return 0;
+  return te_align_up(planes_bytes(T, K), 256) + kPartialBytes + kFlagBytes;
+}
+
+extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* w_planes, const float* bias, float* out,
+                              int64_t T, int64_t K, int64_t M, void* ws, size_t ws_bytes, te_stream_t stream_) {
+  if ((!X && !x_planes) || !w_planes || !out) return TE_ERR_INVALID_ARG;
+  if (!te_gemm_x6_supported(T, K, M)) return TE_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < te_gemm_x6_workspace_bytes(T, K, M) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
+  if ((X && !te_aligned16(X)) || !te_aligned16(out) || !te_aligned16(w_planes) || (bias && !te_aligned16(bias)) ||
+      (x_planes && !te_aligned16(x_planes)))
+    return TE_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned char* q = (unsigned char*)ws;
+  unsigned char* Xs = q;
+  q += te_align_up(planes_bytes(T, K), 256);
+  float* partial = (float*)q;
+  q += kPartialBytes;
+  unsigned* flag_words = (unsigned*)q;
+  zero_words_kernel<<<dim3(kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
+  if (!x_planes) {
+    int rc = te_linear_x6_split_matrix_f32(X, T, K, 0, Xs, planes_bytes(T, K), stream_);
+    if (rc != TE_OK) return rc;
+    x_planes = Xs;
+  }
+  int wm = (M % 256 == 0) ? 2 : 1;
+  if (wm == 2 && te_ceil_div(T, kTileT) * (M / 256) < 192) wm = 1;
+  X6Params p{};
+  p.T = T;
+  p.in_f = (int)K;
+  p.out_f = (int)M;
+  p.ncb = (int)te_ceil_div(T, 32);
+  p.ntn = (int)te_ceil_div(T, kTileT);
+  p.partial = partial;
+  p.flags = flag_words;
+  p.bias = bias;
+  p.out = out;
+  p.A = (const unsigned char*)w_planes;
+  p.B = (const unsigned char*)x_planes;
+  p.nks = (int)(K / 16);
+  p.a_group_stride = (int64_t)p.nks * kRB;
+  p.b_rb_stride = (int64_t)p.nks * kRB;
+  p.ntm = (int)(M / (128 * wm));
+  int rc = (wm == 2) ? launch_x6<2, MODE_G>(p, stream) : launch_x6<1, MODE_G>(p, stream);
+  if (rc != TE_OK) return rc;
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }

@@ -142,6 +142,54 @@ def x6_weight_planes(W: Tensor, cache: Optional[dict] = None) -> Tensor:
     return planes
 
 
+# The forward output and the input gradient of a Linear layer on the x6 kernels (te_gemm_x6_f32) under
+# ops.USE_FUSED_PRODUCERS.  OPT-IN (TE_X6_GEMM=1): measured on the MI355X the tuned stock fp32 GEMMs (TunableOp: 117-148 TF)
+# still win by 2 ms per ViT-B/16 batch-64 step -- each product here pays a split pass over its activation operand first
+# (DESIGN.md section 6); the default stays rocBLAS / hipBLASLt.
+USE_X6_GEMM = os.environ.get("TE_X6_GEMM", "0") not in ("", "0")
+
+
+def x6_matrix_planes(W: Tensor, transposed: bool, cache: Optional[dict] = None) -> Tensor:
+    """Signed bf16 operand planes of W [out, in] (transposed=False: rows = out, the forward product's weight side) or of
+    W^T (transposed=True: rows = in, the input gradient's), built once per weight version (cache as x6_weight_planes)."""
+    out_f, in_f = W.shape
+    name = "x6_gemm_planes_T" if transposed else "x6_gemm_planes"
+    key = (W.data_ptr(), W._version, out_f, in_f, str(W.device))
+    if cache is not None:
+        hit = cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    Wc = _c(W.detach())
+    rows, K = (in_f, out_f) if transposed else (out_f, in_f)
+    with _on_device(Wc) as lib:
+        planes = _ws(lib.te_linear_x6_planes_bytes(rows, K), Wc)
+        _lib.check(lib.te_linear_x6_split_matrix_f32(_ptr(Wc), rows, K, int(transposed), _ptr(planes), planes.numel(),
+                                                     _stream(Wc)), "te_linear_x6_split_matrix_f32")
+    if cache is not None:
+        cache[name] = (key, planes)
+    return planes
+
+
+def gemm_x6_supported(T: int, K: int, M: int) -> bool:
+    return bool(_lib.load().te_gemm_x6_supported(int(T), int(K), int(M)))
+
+
+def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_name: str = "gemm_x6") -> Tensor:
+    """out [..., M] = X [..., K] . W^T + bias with W as signed planes of an [M, K] matrix (x6_matrix_planes)."""
+    K = X.shape[-1]
+    lead = X.shape[:-1]
+    Xc = _c(X).reshape(-1, K)
+    T = Xc.shape[0]
+    out = torch.empty((T, M), dtype=torch.float32, device=X.device)
+    bc = None if bias is None else _c(bias.detach())
+    with _on_device(Xc) as lib:
+        ws = _ws(lib.te_gemm_x6_workspace_bytes(T, K, M), Xc)
+        with _timed(timer_name, 12.0 * T * K * M, 10.0 * T * K + 6.0 * K * M + 4.0 * T * M):
+            _lib.check(lib.te_gemm_x6_f32(_ptr(Xc), None, _ptr(w_planes), _ptr(bc), _ptr(out), T, K, M, _ptr(ws),
+                                          ws.numel(), _stream(Xc)), "te_gemm_x6_f32")
+    return out.reshape(*lead, M)
+
+
 def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant="ours",
                    Y: Optional[Tensor] = None, bias: Optional[Tensor] = None, cache: Optional[dict] = None) -> Tensor:
     """Linear.relprop: R [..., out], X [..., in], W [out, in] -> [..., in].

@@ -71,6 +71,37 @@ class _Gelu(torch.autograd.Function):
         return ops.gelu_backward(dy, x)
 
 
+class _Linear(torch.autograd.Function):
+    """nn.Linear (modules/layers_ours.py:207: ``class Linear(nn.Linear, RelProp)``) on the split-operand bf16 kernels of
+    csrc/te_linear_x6.hip: y = x W^T + b and, backward, d_x = d_y W -- each fp32 operand as three bf16 planes, six
+    partial products, fp32 accumulation (fp32-class accuracy: tests/test_gpu_producers.py).  No weight / bias gradient
+    (the explanation differentiates w.r.t. activations only; eval mode only, like the LayerNorm producer)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        ctx.weight, ctx.cache = weight, cache
+        return ops.gemm_x6(x, ops.x6_matrix_planes(weight, False, cache), bias, weight.shape[0], "linear_forward_x6")
+
+    @staticmethod
+    def backward(ctx, dy):
+        w = ctx.weight
+        return ops.gemm_x6(dy, ops.x6_matrix_planes(w, True, ctx.cache), None, w.shape[1], "linear_backward_x6"), None, None, None
+
+
+def linear_usable(x: torch.Tensor, lin) -> bool:
+    if not (ops.USE_FUSED_PRODUCERS and ops.USE_X6_GEMM and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
+            and not lin.training and x.dim() >= 2):
+        return False
+    out_f, in_f = lin.weight.shape
+    T = x.numel() // in_f
+    # both directions on the x6 kernels, or neither (a stock forward with an x6 backward would mix two roundings)
+    return T >= 256 and ops.gemm_x6_supported(T, in_f, out_f) and ops.gemm_x6_supported(T, out_f, in_f)
+
+
+def linear(x, lin, cache):
+    return _Linear.apply(x, lin.weight, lin.bias, cache)
+
+
 def layer_norm(x, norm):
     return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
 

@@ -136,6 +136,12 @@ def x6_cache(module) -> dict:
 class Linear(nn.Linear, RelProp):
     """layers_ours.py:207-230 / layers_lrp.py:188-211 -> te_linear_relprop_f32."""
 
+    def forward(self, x):
+        from . import producers                      # 8f.1: forward / input gradient on te_gemm_x6_f32
+        if producers.linear_usable(x, self):
+            return producers.linear(x, self, x6_cache(self))
+        return super().forward(x)
+
     def relprop(self, R, alpha):
         # self.Y (the forward output, cached by forward_hook like the reference does) lets the kernel derive
         # Z = X+ W+^T + X- W-^T from one product instead of two
