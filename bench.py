@@ -486,7 +486,7 @@ def main():
     from transformer_explainability_amd.generators import GraphedCall
 
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    rig = "TE_DEVICE_OVERRIDE" in os.environ
+    rig = "TE_DEVICE_OVERRIDE" in os.environ or os.environ.get("TE_DIST_BACKEND") == "gloo"
     if torch.cuda.device_count() < world and not rig:
         sys.exit(f"rank {rank}: {torch.cuda.device_count()} GPU(s) visible for {world} ranks")
     te._lib.require_device()
@@ -638,7 +638,11 @@ def main():
             "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": X6_DTYPE if args.linear == "x6" else "f32", "data": "synthetic",
-            "config": {"workload": f"{wl.title} batch {B} per GPU on {world}xMI355X: PyTorch-ROCm fwd + attn-grad bwd "
+            **({"rig": True, "rig_note": "test rig: all ranks share ONE GPU over gloo -- not a multi-GPU measurement"}
+               if rig else {}),
+            "config": {"workload": f"{wl.title} batch {B} per GPU on "
+                                   f"{(str(world) + ' ranks sharing one MI355X (rig)') if rig else (str(world) + 'xMI355X')}: "
+                                   f"PyTorch-ROCm fwd + attn-grad bwd "
                                    f"({fused_note}) + fp32 relprop/head-mean/rollout HIP kernels"
                                    f"{' (Linear rules: fp32 operands as three bf16 planes on bf16 MFMAs)' if args.linear == 'x6' else ''} (BASELINE.json "
                                    f"configs[{idx}], sharded by sample)",

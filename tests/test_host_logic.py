@@ -322,3 +322,18 @@ def test_reference_stage_matches_checkout():
         for rel, h in man.items():
             with open(os.path.join("/root/reference", rel), "rb") as f:
                 assert hashlib.sha256(f.read()).hexdigest() == h, rel
+
+
+def test_index_select_host_copy_follows_in_place_edits():
+    """the host copy of a device / tensor index is keyed on identity AND version counter, so
+    ``idx.fill_(k)`` between forwards is seen (the cached value used to go stale silently)."""
+    import torch
+    from transformer_explainability_amd import rules
+    m = rules.IndexSelect()
+    x = torch.randn(2, 5, 4)
+    idx = torch.tensor([0])
+    m(x, 1, idx)
+    assert m._index_host == 0
+    idx.fill_(3)
+    y = m(x, 1, idx)
+    assert m._index_host == 3 and torch.equal(y, x[:, 3:4])

@@ -76,3 +76,77 @@ def test_world2_gloo_matches_single_process(tmp_path):
         assert torch.equal(got["full"], single), f"rank {rank}: gathered maps differ from the single-process run"
     assert torch.load(os.path.join(str(tmp_path), "rank0.pt"))["idx"] == [0, 1, 2]
     assert torch.load(os.path.join(str(tmp_path), "rank1.pt"))["idx"] == [3, 4]
+
+
+# ------------------------------------------------------------------------------------------ the sweep layout
+_COLLECTIVES = ("all_gather", "all_gather_into_tensor", "all_gather_object", "all_reduce", "broadcast", "reduce",
+                "reduce_scatter", "reduce_scatter_tensor", "all_to_all", "all_to_all_single", "gather", "scatter", "send",
+                "recv", "isend", "irecv", "broadcast_object_list")
+
+
+def _sweep_worker(rank, world, port, n_items, out_dir):
+    """BASELINE.json configs[4]'s layout on two CPU ranks: shard the dataset (block partition), explain + store the own
+    shard (sweep.py), gather the maps -- with every torch.distributed collective counted."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from oracle_backend import oracle_ops
+    from test_sweep import ToyImages, _generators
+    from transformer_explainability_amd import parallel
+    from transformer_explainability_amd.sweep import ResultsStore, SaliencySweep, shard_batches
+    r, w, _ = parallel.init_distributed(backend="gloo")
+    calls = {}
+    for name in _COLLECTIVES:
+        fn = getattr(dist, name, None)
+        if fn is None:
+            continue
+
+        def counted(*a, _fn=fn, _name=name, **k):
+            calls[_name] = calls.get(_name, 0) + 1
+            return _fn(*a, **k)
+        setattr(dist, name, counted)
+    ds = ToyImages(n_items)
+    dev = torch.device("cpu")
+    with oracle_ops():
+        lrp, orig, base = _generators(dev)
+        sw = SaliencySweep("transformer_attribution", lrp=lrp, orig_lrp=orig, baselines=base, device=dev)
+        batches, lo, hi = shard_batches(ds, 2, r, w)
+        with ResultsStore(out_dir, len(ds), (3, 32, 32), (1, 32, 32), lo, hi, backend="npy") as store:
+            sw.run(batches, store, r, w)
+        local = torch.as_tensor(store_vis(out_dir, lo, hi))
+    in_data_path = dict(calls)                      # collectives issued while explaining / storing: must be none
+    full = parallel.gather_maps(local.reshape(hi - lo, -1), n_items)
+    torch.save({"full": full, "lo": lo, "hi": hi, "data_path_calls": in_data_path, "calls": dict(calls)},
+               os.path.join(out_dir, f"sweep_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def store_vis(out_dir, lo, hi):
+    import numpy as np
+    return np.load(os.path.join(out_dir, "results", f"vis.{lo:09d}-{hi:09d}.npy"))
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_sweep_layout_and_single_collective(tmp_path):
+    """The 50k-image sweep's layout (BASELINE.json configs[4]) at toy size on two gloo ranks: ragged block
+    shards, per-rank result stores, ONE collective in the whole run (the all_gather of the finished maps) and none in the
+    data path; the gathered maps are in global order and equal the stores read back through ImagenetResults."""
+    n_items = 7
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    port = _free_port()
+    mp.spawn(_sweep_worker, args=(2, port, n_items, str(tmp_path)), nprocs=2, join=True)
+    from transformer_explainability_amd.sweep import ImagenetResults
+    res = ImagenetResults(str(tmp_path))
+    assert len(res) == n_items
+    stored = torch.stack([res[i][1].reshape(-1) for i in range(n_items)])
+    got = [torch.load(os.path.join(str(tmp_path), f"sweep_rank{r}.pt")) for r in range(2)]
+    assert (got[0]["lo"], got[0]["hi"], got[1]["lo"], got[1]["hi"]) == (0, 4, 4, 7)
+    for r in range(2):
+        assert got[r]["data_path_calls"] == {}, got[r]["data_path_calls"]
+        total = sum(got[r]["calls"].values())
+        assert total == 1 and set(got[r]["calls"]) <= {"all_gather", "all_gather_into_tensor"}, got[r]["calls"]
+        assert torch.equal(got[r]["full"], stored), f"rank {r}: gathered maps are not the stores in global order"

@@ -98,16 +98,23 @@ def linear_usable(x: torch.Tensor, lin) -> bool:
     return T >= 256 and ops.gemm_x6_supported(T, in_f, out_f) and ops.gemm_x6_supported(T, out_f, in_f)
 
 
+# The parameters enter the producer nodes DETACHED: these nodes produce the input gradient only, and autograd is told so
+# (a caller who differentiates w.r.t. LayerNorm / Linear parameters under ops.USE_FUSED_PRODUCERS gets "no gradient" for
+# them from autograd itself instead of a silent None from a node that claimed to be differentiable).
+def _d(t):
+    return None if t is None else t.detach()
+
+
 def linear(x, lin, cache):
-    return _Linear.apply(x, lin.weight, lin.bias, cache)
+    return _Linear.apply(x, _d(lin.weight), _d(lin.bias), cache)
 
 
 def layer_norm(x, norm):
-    return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+    return _LayerNorm.apply(x, _d(norm.weight), _d(norm.bias), norm.eps)
 
 
 def residual_layer_norm(x, norm):
-    return _ResidualLayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+    return _ResidualLayerNorm.apply(x, _d(norm.weight), _d(norm.bias), norm.eps)
 
 
 def gelu(x):

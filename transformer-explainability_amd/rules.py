@@ -245,10 +245,13 @@ class IndexSelect(RelProp):
         # capturable in a HIP graph
         if not torch.is_tensor(indices):
             self._index_host = int(indices)
-        elif indices.numel() == 1 and (not indices.is_cuda or getattr(self, "_index_src", None) is not indices):
+        elif indices.numel() == 1 and (not indices.is_cuda or getattr(self, "_index_src", None) is not indices
+                                       or getattr(self, "_index_version", None) != indices._version):
+            # (identity AND version counter: an in-place edit of the index buffer, ``idx.fill_(k)``, refreshes the copy)
             if not (indices.is_cuda and torch.cuda.is_current_stream_capturing()):
                 self._index_host = int(indices)
                 self._index_src = indices
+                self._index_version = indices._version
         return torch.index_select(inputs, dim, indices.reshape(-1) if torch.is_tensor(indices) else indices)
 
     def relprop(self, R, alpha):
@@ -256,7 +259,8 @@ class IndexSelect(RelProp):
         if self.dim != 1 or self.X.dim() != 3 or (torch.is_tensor(idx) and idx.numel() != 1):
             raise NotImplementedError("IndexSelect.relprop: only dim=1 with a single index is accelerated")
         host = getattr(self, "_index_host", None)
-        if host is None or (torch.is_tensor(idx) and getattr(self, "_index_src", idx) is not idx):
+        if host is None or (torch.is_tensor(idx) and (getattr(self, "_index_src", idx) is not idx
+                                                      or getattr(self, "_index_version", idx._version) != idx._version)):
             host = int(idx)                                        # (device sync; not capturable)
         return ops.index_select_relprop(R, self.X, host)
 
