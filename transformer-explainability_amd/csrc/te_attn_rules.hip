@@ -851,11 +851,15 @@ constexpr size_t kLdsFwd = (size_t)(NJF * 64 + 64 * WLD + TI * 64 + TI * WLD) * 
 // row tile is dominated by per-tile costs that do not shrink with the tile, so halving the keys
 // doubles them.  TE_ATTN_JG = 128 | 192 | 256 pins the group size (tuning).
 inline void groups_for(int64_t N, int& ng, int& jg, int jmax = 0) {
+#ifdef TE_STUDY      // measurement builds only: the shipped library reads no environment
   static const int pinned = [] {
     const char* e = getenv("TE_ATTN_JG");
     const int v = e ? atoi(e) : 0;
     return (v == 128 || v == 192 || v == 256) ? v : 0;
   }();
+#else
+  constexpr int pinned = 0;
+#endif
   if (jmax == 0) jmax = pinned ? pinned : 256;
   ng = (int)((N + jmax - 1) / jmax);
   jg = (int)(((N + ng - 1) / ng + 63) & ~(int64_t)63);      // equal groups, whole 64-key units (the LDS row stride)
@@ -869,18 +873,26 @@ inline void allow_lds(K kern, size_t bytes) {
 }  // namespace
 
 // tuning aid: device buffer of 2 x 64 counters (AV kernel, QK kernel) the next launches accumulate into; NULL = off
+#ifdef TE_STUDY      // measurement builds only (scripts/attn_phase_profile.py): the shipped library has no mutable globals
 static long long* g_prof = nullptr;
 }  // namespace te_attn_rules
 extern "C" void te_attn_rules_profile(long long* device_buffer) { te_attn_rules::g_prof = device_buffer; }
 namespace te_attn_rules {
+#else
+static long long* const g_prof = nullptr;
+#endif
 
 bool enabled() {
   // TE_ATTN_IMPL=tiles selects the 64 x 64-tile kernels of te_attn_mfma.hip (kept as the on-device cross-check)
+#ifdef TE_STUDY
   static const bool on = [] {
     const char* e = getenv("TE_ATTN_IMPL");
     return !(e && !strcmp(e, "tiles"));
   }();
   return on;
+#else
+  return true;
+#endif
 }
 
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {

@@ -769,10 +769,14 @@ extern "C" int te_gradcam_headmean_f32(const float* grad, const float* cam, floa
   const int64_t NN = N * N;
   int64_t bx = te_ceil_div(NN, (int64_t)kThreads * 4);
   // TE_HEADMEAN_VARIANT (tuning): 0 = grid-stride kernel (<= 2048 blocks), 1 = flat kernel, every head in flight (default)
+#ifdef TE_STUDY      // measurement builds only: the shipped library reads no environment
   static const int variant = [] {
     const char* e = getenv("TE_HEADMEAN_VARIANT");
     return e ? atoi(e) : 1;
   }();
+#else
+  constexpr int variant = 1;
+#endif
   if (variant == 1 && H <= 16 && B <= 65535) {
     const dim3 grid((unsigned)bx, (unsigned)B), blk(kThreads);
     if (H <= 12) headmean_flat_kernel<12><<<grid, blk, 0, stream>>>(grad, cam, out, (int)H, NN);

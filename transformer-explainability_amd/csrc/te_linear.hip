@@ -830,6 +830,7 @@ enum Tile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2 };
 // of 128x64 = 4.64 per CU.  Estimated chip efficiency of a tile = (tiles / CUs) / ceil(tiles / CUs) x a per-tile
 // factor; the best estimate wins.  TE_LINEAR_TILE = 128x128 | 128x64 | 64x64 pins the choice (tuning).
 inline Tile pick_tile(int64_t T, int64_t n_out, bool one_product = false) {
+#ifdef TE_STUDY      // measurement builds only (TE_BUILD_DEFINES=TE_STUDY): the shipped library reads no environment
   static const int pinned = [] {
     const char* e = getenv("TE_LINEAR_TILE");
     if (!e) return -1;
@@ -839,6 +840,7 @@ inline Tile pick_tile(int64_t T, int64_t n_out, bool one_product = false) {
     return -1;
   }();
   if (pinned >= 0) return (Tile)pinned;
+#endif
   auto eff = [&](int bm, int bn, double factor) {
     const int64_t tiles = te_ceil_div(T, bm) * te_ceil_div(n_out, bn);
     return factor * ((double)tiles / kCUs) / (double)te_ceil_div(tiles, kCUs);
@@ -869,6 +871,7 @@ inline void launch_k1(const float* X, const float* W, const float* R, const floa
   if constexpr (ZM == ZM_FWD) {
     // TE_ZFWD_VARIANT (tuning study, profiles/r01_zfwd_variants.log): 0 = per-element epilogue, distance-1 prefetch;
     // 1 = batched epilogue loads (-3.5 %); 2 = 1 + prefetch distance 2 (-6.3 %, default)
+#ifdef TE_STUDY      // variants 0 / 1 (one of which spills) exist in measurement builds only
     static const int var = [] {
       const char* e = getenv("TE_ZFWD_VARIANT");
       return e ? atoi(e) : 2;
@@ -876,8 +879,10 @@ inline void launch_k1(const float* X, const float* W, const float* R, const floa
     switch (var) {
       case 0: return launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
       case 1: return launch_k1v<ZM, SWAP, BM, BN, 1>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
-      default: return launch_k1v<ZM, SWAP, BM, BN, 2>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
+      default: break;
     }
+#endif
+    return launch_k1v<ZM, SWAP, BM, BN, 2>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
   }
   launch_k1v<ZM, SWAP, BM, BN, 0>(X, W, R, Y, bias, S1, S2, T, in_f, out_f, stream, rs);
 }
@@ -888,7 +893,7 @@ inline void launch_k2(const float* S, const float* W, const float* X, float* out
   const int ntiles = (int)te_ceil_div(T, BM) * nbn;
   constexpr size_t lds = k2_lds<BM, BN>();
   if constexpr (MODE == 0 && !SWAP && !ACCUM) {
-    // TE_CPASS_GLDS=1: direct-to-LDS staging of the interior tiles (tuning study; see glds16)
+#ifdef TE_STUDY      // TE_CPASS_GLDS=1: direct-to-LDS staging of the interior tiles (tuning study; see glds16) -- measurement builds
     static const bool glds = [] {
       const char* e = getenv("TE_CPASS_GLDS");
       return e && atoi(e) != 0;
@@ -899,6 +904,7 @@ inline void launch_k2(const float* S, const float* W, const float* X, float* out
           S, W, X, out, T, out_f, in_f, nbn, ntiles, scale, zb);
       return;
     }
+#endif
   }
   allow_lds(linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN>, lds);
   linear_k2_kernel<MODE, SWAP, ACCUM, BM, BN><<<dim3((unsigned)ntiles), dim3(kThreads), lds, stream>>>(
