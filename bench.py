@@ -64,6 +64,12 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def _resolve(args):
+    if args.overlap_backward == "auto":
+        args.overlap_backward = "on" if args.config == "vit_b16_224" else "off"
+    return args
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,10 +93,11 @@ def parse_args(argv=None):
     ap.add_argument("--prune", choices=["on", "off"], default="off",
                     help="skip the relprop rules and attention gradients of the blocks below --start-layer (their "
                          "attn_cam never reaches the map); off = every block, as the reference does")
-    ap.add_argument("--overlap-backward", choices=["on", "off"], default="on",
-                    help="run the relprop rules on a side stream beside the attention-gradient backward pass (default on "
-                         "since round 3: bitwise-equal maps, graph-capturable, +2.5 % -- 773.6 vs 754.8 maps/s; the "
-                         "eager probe step that feeds the roofline block always runs serially)")
+    ap.add_argument("--overlap-backward", choices=["auto", "on", "off"], default="auto",
+                    help="run the relprop rules on a side stream beside the attention-gradient backward pass: bitwise-equal "
+                         "maps, graph-capturable.  auto (default since round 3) = on for the headline configuration (+2.5 %: "
+                         "773.6 vs 754.8 maps/s), off for ViT-L/384 (-3 %) and BERT-512 (neutral); the eager probe step "
+                         "that feeds the roofline block always runs serially")
     ap.add_argument("--inflight", type=int, default=1,
                     help="consecutive steps (batches) in flight, each on its own HIP stream (eager launches)")
     ap.add_argument("--linear", choices=["x6", "fp32"], default="x6",
@@ -98,11 +105,13 @@ def parse_args(argv=None):
                          "products, fp32 accumulation (csrc/te_linear_x6.hip; fp32-class accuracy, asserted by the parity "
                          "tests); fp32 = the fp32-MFMA kernels of csrc/te_linear.hip.  With x6 the line also carries the "
                          "fp32-MFMA throughput of the same workload from a second timed run (config.fp32_mfma_*)")
+    ap.add_argument("--x6-tile", choices=["auto", "128", "256"], default="auto",
+                    help="tile geometry of the x6 Linear kernels (measurement knob: the maps do not depend on it)")
     ap.add_argument("--producers", choices=["stock", "fused"], default="fused",
                     help="fused (default): the attention blocks' forward and attention-gradient backward run on the "
                          "hand-written producer kernels (SURVEY.md 8f.1: head dim 64; N <= 224 one workgroup per head, N <= 640 "
                          "row tiles -- ViT-B/16 224^2, ViT-L/16 384^2 and BERT-512 alike); stock: PyTorch-ROCm everywhere")
-    return ap.parse_args(argv)
+    return _resolve(ap.parse_args(argv))
 
 
 # --------------------------------------------------------------------------------------------------------- launcher
@@ -500,6 +509,7 @@ def main():
     if args.producers == "fused":
         ops.USE_FUSED_PRODUCERS = True
     ops.USE_LINEAR_X6 = args.linear == "x6"
+    ops.X6_TILE = {"auto": 0, "128": 1, "256": 2}[args.x6_tile]
 
     wl = Workload(args, rank, dev)
     B = wl.B

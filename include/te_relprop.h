@@ -272,11 +272,13 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
  *   te_linear_relprop_x6_f32           x_planes = NULL: |X| is split into the workspace first.
  * Workspace = |X| planes, S planes (the Z-pass writes S only in plane form), 64 MiB of accumulator hand-over between
  * workgroups that share a tile (sequential stream-K: one k-ordered chain per output wherever a tile is cut), flags.
- * flags: TE_X6_TILE_AUTO (256 weight rows per tile, one 512-thread workgroup per CU, where the shape allows; the result
- * does not depend on the tile geometry, bit for bit), TE_X6_TILE_128 (128 weight rows, two 256-thread workgroups per CU).
+ * flags: TE_X6_TILE_AUTO (per pass: 256 weight rows per tile / one 512-thread workgroup per CU where that gives every CU
+ * a tile, else 128 rows / two 256-thread workgroups per CU; the result does not depend on the tile geometry, bit for
+ * bit), TE_X6_TILE_128 / TE_X6_TILE_256 pin it.
  * te_linear_relprop_x6_check (synchronises) returns 1 if a bounded hand-over wait of the last call expired. */
 #define TE_X6_TILE_AUTO 0
 #define TE_X6_TILE_128 1
+#define TE_X6_TILE_256 2
 /* optional phase mask (measurement: one phase per call on the same workspace, in this order); 0 = the whole rule */
 #define TE_X6_PHASE_SPLIT 4    /* clear the flags, |X| -> planes (unless x_planes is given) */
 #define TE_X6_PHASE_Z 8        /* S planes */

@@ -182,7 +182,7 @@ def test_linear_layer_on_producers():
         assert "x6_gemm_planes" in rules.x6_cache(lin)
         (dx1,) = torch.autograd.grad(y1, x, g)
         check("producer.linear.layer.y", y1, y0, 2e-6)
-        check("producer.linear.layer.dx", dx1, dx0, 2e-6)
+        check("producer.linear.layer.dx", dx1, dx0, 5e-6)      # (K = 3072: two fp32-class roundings)
         assert lin.Y is y1 and lin.X.shape == x.shape
         small = lin(x[:1])                       # 197 rows: stock kernels
         assert torch.equal(small, torch.nn.functional.linear(x[:1], lin.weight, lin.bias))

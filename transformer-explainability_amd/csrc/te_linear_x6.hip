@@ -827,15 +827,20 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     }
     x_planes = Xs;
   }
-  int wm = pick_wm(in_f, out_f);
-  if ((flags & 3) == TE_X6_TILE_128 && wm == 2) wm = 1;      // 128-row weight tiles, two workgroups per CU
-  // few rows: 256-row tiles would leave CUs without a workgroup (the result does not depend on the geometry)
-  if (wm == 2 && te_ceil_div(T, kTileT) * (std::min(in_f, out_f) / 256) < 192) wm = 1;
+  // Tile geometry per pass (the result does not depend on it, bit for bit): 256 weight rows / one 512-thread workgroup per
+  // CU where that gives every CU at least one tile, else 128 rows / two 256-thread workgroups per CU.
+  const int wm_max = pick_wm(in_f, out_f);
+  const int64_t ntn_ = te_ceil_div(T, kTileT);
+  int wm_z = (wm_max == 2 && ntn_ * (out_f / 256) >= 256) ? 2 : 1;
+  int wm_c = (wm_max == 2 && ntn_ * (in_f / 128) >= 256) ? 2 : 1;
+  if ((flags & 3) == TE_X6_TILE_128) wm_z = wm_c = 1;
+  if ((flags & 3) == TE_X6_TILE_256) wm_z = wm_c = wm_max;
 #ifdef TE_X6_STUDY
   const int study = (flags >> 5) & 7;      // study builds: run ablation `study` of the main loop instead
   flags &= 0x1f;
 #endif
   if ((flags & ~0x1f) != 0 || (flags & 3) == 3) return TE_ERR_INVALID_ARG;
+  int wm = 0;
   X6Params p{};
   p.T = T;
   p.in_f = (int)in_f;
@@ -860,6 +865,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     p.nks = (int)(in_f / 16);
     p.a_group_stride = (int64_t)p.nks * kRB;
     p.b_rb_stride = (int64_t)p.nks * kRB;
+    wm = wm_z;
     p.ntm = (int)(out_f / (128 * wm));
     p.flags = flag_words;
 #ifdef TE_X6_STUDY
@@ -881,6 +887,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     p.nks = (int)(out_f / 16);
     p.a_group_stride = (int64_t)p.nks * 2 * kRB;
     p.b_rb_stride = (int64_t)p.nks * kRB;
+    wm = wm_c;
     p.ntm = (int)(in_f / (64 * wm));
     p.flags = flag_words + kFlagBytes / 4;
 #ifdef TE_X6_STUDY
