@@ -34,6 +34,7 @@
 //                   ViT-B batch 64 the 256-wide tiles of the eight launches of a block fill 59-94 % of whole rounds).
 //                   Waits only ever go to a LOWER workgroup index of the same XCD slot order.
 #include <algorithm>
+#include <cstdlib>
 
 #include "te_common.h"
 
@@ -155,6 +156,7 @@ struct X6Params {
   int64_t b_rb_stride;         // bytes between consecutive 32-row blocks of B  = nks * 3 KiB
   int nks;                     // K / 16
   int ntm, ntn;                // tiles along the weight side / the activation side
+  int t_fast;                  // tile order inside the launch: 0 = weight side fastest, 1 = activation side fastest
   int ncb;                     // 32-row blocks of the activation side = ceil(T / 32)
   int64_t T;
   int in_f, out_f;
@@ -247,7 +249,12 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       tile = full0 + seq - (head ? 1 : 0), k0 = 0, k1 = nks;
     }
     tile += tx0;
-    const int tn = tile / p.ntm, tm = tile - tn * p.ntm;
+    int tn, tm;
+    if (p.t_fast) {
+      tm = tile / p.ntn, tn = tile - tm * p.ntn;
+    } else {
+      tn = tile / p.ntm, tm = tile - tn * p.ntm;
+    }
 
     // ---- what this wave stages per step: the three planes of ONE weight-side 32-row block [one sign] and of PBW
     //      activation-side blocks -- each 3 KiB contiguous in memory and in the stage; wave-uniform pointers ----
@@ -353,46 +360,68 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       // The order below is pinned with sched_barrier: left to itself hipcc's scheduler flips between an order that
       // chains dependent MFMAs two apart behind piecemeal LDS waits and a good one on unrelated source edits (+-17 % on
       // the whole kernel, measured).  Six partial products per block, smallest first (PA / PB); one ROUND = the same
-      // partial product of all eight blocks (eight independent accumulators between dependent MFMAs).  The fragment
-      // reads are issued in the order the rounds consume them: round 0 needs plane 1 of both sides, round 1 planes
-      // (0, 2), round 2 planes (2, 0); rounds 3-5 reuse what is resident.
+      // partial product of all eight blocks (eight independent accumulators between dependent MFMAs), so the order of
+      // the blocks inside a round is free: it is chosen so that every MFMA needs at most ONE fragment the previous ones
+      // did not ((a0,b0) (a1,b0) (a1,b1) (a0,b1) (a2,b1) (a2,b0) (a3,b0) (a3,b1)), the fragment reads are issued in that
+      // order (b0 a0 a1 b1 a2 a3; round 0 = plane 1 of both sides, round 1 planes (0, 2), round 2 planes (2, 0); rounds
+      // 3-5 reuse what is resident), three to six at a time between the MFMAs, and each MFMA waits for exactly its own
+      // operands.  After the barrier all eight waves read at once and the LDS delivers one 1 KiB fragment per 8 clocks:
+      // waiting for a whole round (6 fragments x 8 waves) before the first MFMA idled the pipe for ~13 % of the step.
       constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
-      // the next step's stage is requested FIRST: with a direct-to-LDS load between the fragment reads and the MFMAs
-      // hipcc waits lgkmcnt(0) before the first MFMA instead of lgkmcnt(12) / (6) / (0) round by round
-      if constexpr (FULL) stage_in(st ^ 1, (ks + 1 < k1) ? 1 : 0);
-      __builtin_amdgcn_sched_barrier(0);
       // The reads are inline asm with hand-counted waits (guide 5.7): hipcc waits lgkmcnt(0) before the first MFMA once a
-      // direct-to-LDS load is in flight; lgkmcnt counts LDS returns in order, so 12 / 6 / 0 outstanding = round 0 / 1 / 2
-      // operands present.  (Waits the compiler adds for its own LDS operations can only be longer than needed.)
-      if constexpr (STUDY != 3) {
-        const unsigned aA = (unsigned)(uintptr_t)sA, aB = (unsigned)(uintptr_t)sB;
+      // direct-to-LDS load is in flight.  lgkmcnt counts LDS returns in order: with I reads issued, fragment n (0-based)
+      // is present once at most I - 1 - n are outstanding.  (Waits the compiler adds for its own LDS operations can only
+      // be longer than needed.)
+      const unsigned aA = (unsigned)(uintptr_t)sA, aB = (unsigned)(uintptr_t)sB;
+#define X6_SB __builtin_amdgcn_sched_barrier(0)
+#define X6_RDB(ni, r) \
+  if constexpr (STUDY != 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[ni][PB[r]]) : "v"(aB), "i"((ni) * kRB + PB[r] * kFrag))
+#define X6_RDA(mi, r) \
+  if constexpr (STUDY != 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[mi][PA[r]]) : "v"(aA), "i"((mi) * kRB + PA[r] * kFrag))
+#define X6_WAIT(n)                                                           \
+  X6_SB;                                                                     \
+  if constexpr (STUDY != 3) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+  X6_SB
+#define X6_MM(mi, ni, q) acc[mi][ni] = TE_MFMA_BF16(a[mi][PA[q]], b[ni][PB[q]], acc[mi][ni])
+#define X6_RD_HEAD(r) X6_SB; X6_RDB(0, r); X6_RDA(0, r); X6_RDA(1, r); X6_SB
+#define X6_RD_TAIL(r) X6_SB; X6_RDB(1, r); X6_RDA(2, r); X6_RDA(3, r); X6_SB
+      X6_RD_HEAD(0);
+      X6_RD_TAIL(0);                                                 // 6 issued
+      // the next step's stage is requested before the first MFMA (a direct-to-LDS load between MFMAs costs issue slots)
+      if constexpr (FULL) stage_in(st ^ 1, (ks + 1 < k1) ? 1 : 0);
+      X6_WAIT(4); X6_MM(0, 0, 0);
+      X6_WAIT(3); X6_MM(1, 0, 0);
+      X6_WAIT(2); X6_MM(1, 1, 0); X6_MM(0, 1, 0);
+      X6_RD_HEAD(1);                                                 // 9 issued
+      X6_WAIT(4); X6_MM(2, 1, 0); X6_MM(2, 0, 0);
+      X6_WAIT(3); X6_MM(3, 0, 0); X6_MM(3, 1, 0);
+      X6_RD_TAIL(1);                                                 // 12 issued
+      X6_WAIT(4); X6_MM(0, 0, 1);
+      X6_WAIT(3); X6_MM(1, 0, 1);
+      X6_WAIT(2); X6_MM(1, 1, 1); X6_MM(0, 1, 1);
+      X6_RD_HEAD(2);                                                 // 15 issued
+      X6_WAIT(4); X6_MM(2, 1, 1); X6_MM(2, 0, 1);
+      X6_WAIT(3); X6_MM(3, 0, 1); X6_MM(3, 1, 1);
+      X6_RD_TAIL(2);                                                 // 18 issued
+      X6_WAIT(4); X6_MM(0, 0, 2);
+      X6_WAIT(3); X6_MM(1, 0, 2);
+      X6_WAIT(2); X6_MM(1, 1, 2); X6_MM(0, 1, 2);
+      X6_WAIT(1); X6_MM(2, 1, 2); X6_MM(2, 0, 2);
+      X6_WAIT(0); X6_MM(3, 0, 2); X6_MM(3, 1, 2);
+      X6_SB;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[ni][PB[r]]) : "v"(aB), "i"(ni * kRB + PB[r] * kFrag));
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[mi][PA[r]]) : "v"(aA), "i"(mi * kRB + PA[r] * kFrag));
-        }
-      } else {
-        (void)sA;
-        (void)sB;
+      for (int q6 = 3; q6 < 6; ++q6) {
+        X6_MM(0, 0, q6); X6_MM(1, 0, q6); X6_MM(1, 1, q6); X6_MM(0, 1, q6);
+        X6_MM(2, 1, q6); X6_MM(2, 0, q6); X6_MM(3, 0, q6); X6_MM(3, 1, q6);
+        X6_SB;
       }
-#pragma unroll
-      for (int q6 = 0; q6 < 6; ++q6) {
-        if constexpr (STUDY != 3) {
-          if (q6 == 0) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-          if (q6 == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-          if (q6 == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = TE_MFMA_BF16(a[mi][PA[q6]], b[ni][PB[q6]], acc[mi][ni]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+#undef X6_SB
+#undef X6_RDB
+#undef X6_RDA
+#undef X6_WAIT
+#undef X6_MM
+#undef X6_RD_HEAD
+#undef X6_RD_TAIL
       st ^= 1;
     }
 
@@ -763,6 +792,9 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   int wm = (M % 256 == 0) ? 2 : 1;
   if (wm == 2 && te_ceil_div(T, kTileT) * (M / 256) < 192) wm = 1;
   X6Params p{};
+#ifdef TE_X6_STUDY
+  if (const char* e = getenv("TE_X6_ORDER")) p.t_fast = atoi(e);
+#endif
   p.T = T;
   p.in_f = (int)K;
   p.out_f = (int)M;
@@ -778,7 +810,18 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   p.a_group_stride = (int64_t)p.nks * kRB;
   p.b_rb_stride = (int64_t)p.nks * kRB;
   p.ntm = (int)(M / (128 * wm));
-  int rc = (wm == 2) ? launch_x6<2, MODE_G>(p, stream) : launch_x6<1, MODE_G>(p, stream);
+  int rc;
+#ifdef TE_X6_STUDY
+  // study builds (benchmarks/x6_gemm_bench.py): TE_X6_G_WM pins the tile geometry, TE_X6_G_PROF=1 runs the time-stamped kernel
+  if (const char* e = getenv("TE_X6_G_WM")) {
+    wm = (atoi(e) == 2 && M % 256 == 0) ? 2 : 1;
+    p.ntm = (int)(M / (128 * wm));
+  }
+  const char* pe = getenv("TE_X6_G_PROF");
+  if (pe && atoi(pe) == 1) rc = (wm == 2) ? launch_x6<2, MODE_G, 5>(p, stream) : launch_x6<1, MODE_G, 5>(p, stream);
+  else
+#endif
+  rc = (wm == 2) ? launch_x6<2, MODE_G>(p, stream) : launch_x6<1, MODE_G>(p, stream);
   if (rc != TE_OK) return rc;
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
@@ -842,6 +885,9 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   if ((flags & ~0x1f) != 0 || (flags & 3) == 3) return TE_ERR_INVALID_ARG;
   int wm = 0;
   X6Params p{};
+#ifdef TE_X6_STUDY
+  if (const char* e = getenv("TE_X6_ORDER")) p.t_fast = atoi(e);
+#endif
   p.T = T;
   p.in_f = (int)in_f;
   p.out_f = (int)out_f;
