@@ -34,6 +34,7 @@
 //                   ViT-B batch 64 the 256-wide tiles of the eight launches of a block fill 59-94 % of whole rounds).
 //                   Waits only ever go to a LOWER workgroup index of the same XCD slot order.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "te_common.h"
@@ -157,6 +158,8 @@ struct X6Params {
   int nks;                     // K / 16
   int ntm, ntn;                // tiles along the weight side / the activation side
   int t_fast;                  // tile order inside the launch: 0 = weight side fastest, 1 = activation side fastest
+  int whole_tiles;             // 1: ranges are cut at tile boundaries only (all workgroups of a round in k lock-step)
+  int whole_tiles_forced;      // study builds: whole_tiles was set by the caller (TE_X6_SNAP)
   int ncb;                     // 32-row blocks of the activation side = ceil(T / 32)
   int64_t T;
   int in_f, out_f;
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
   auto cut = [&](int s) -> int64_t {
     int64_t b = iters * s / spx;
     const int r = (int)(b % nks);
+    if (p.whole_tiles) return (2 * r < nks) ? b - r : b + (nks - r);
     if (r < kMinFrag) b -= r;
     else if (nks - r < kMinFrag) b += nks - r;
     return b;
@@ -669,6 +673,7 @@ inline size_t planes_bytes(int64_t rows, int64_t K) {
   return (size_t)te_ceil_div(rows, 32) * 32 * (size_t)K * 6;
 }
 constexpr size_t kPartialBytes = (size_t)512 * 256 * 128 * 4;       // grid x threads x 128 floats, both geometries: 64 MiB
+constexpr double kWholeTileSlack = 1.15;                          // whole tiles if ceil(r) <= 1.15 r (launch_x6)
 constexpr size_t kFlagBytes = 65536;                                 // 512 flags + the error word (+ study time stamps), per pass
 
 inline int pick_wm(int64_t in_f, int64_t out_f) {
@@ -691,7 +696,15 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
   const int64_t tiles = (int64_t)p.ntm * p.ntn;
   const int max_spx = (WM == 2) ? 32 : 64;
   const int spx = (int)std::min<int64_t>(max_spx, std::max<int64_t>(1, te_ceil_div(tiles, 8)));
-  kern<<<dim3(8 * spx), dim3(256 * WM), lds, stream>>>(p);
+  // Stream-K or whole tiles?  With equal (tile, k) ranges the workgroups of an XCD sit at different k offsets of their
+  // tiles and nothing one of them fetches is still in the 4 MB L2 when its neighbour needs it; cut at tile boundaries
+  // they run a round in k lock-step on shared operand panels and a K16 step takes 1.9 instead of 2.1-2.6 us (measured,
+  // profiles/r03_x6_whole_tiles.log) -- which pays as long as the last round is nearly full.  r = tiles per workgroup;
+  // whole tiles cost ceil(r) rounds.  Either way every output is the same k-ordered chain: results do not change.
+  X6Params q = p;
+  const double r = (double)tiles / (8.0 * spx);
+  if (!q.whole_tiles_forced) q.whole_tiles = (std::ceil(r) <= kWholeTileSlack * r) ? 1 : 0;
+  kern<<<dim3(8 * spx), dim3(256 * WM), lds, stream>>>(q);
   return TE_OK;
 }
 
@@ -794,6 +807,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   X6Params p{};
 #ifdef TE_X6_STUDY
   if (const char* e = getenv("TE_X6_ORDER")) p.t_fast = atoi(e);
+  if (const char* e = getenv("TE_X6_SNAP")) p.whole_tiles = atoi(e), p.whole_tiles_forced = 1;
 #endif
   p.T = T;
   p.in_f = (int)K;
@@ -887,6 +901,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   X6Params p{};
 #ifdef TE_X6_STUDY
   if (const char* e = getenv("TE_X6_ORDER")) p.t_fast = atoi(e);
+  if (const char* e = getenv("TE_X6_SNAP")) p.whole_tiles = atoi(e), p.whole_tiles_forced = 1;
 #endif
   p.T = T;
   p.in_f = (int)in_f;
