@@ -105,6 +105,11 @@ def parse_args(argv=None):
                          "products, fp32 accumulation (csrc/te_linear_x6.hip; fp32-class accuracy, asserted by the parity "
                          "tests); fp32 = the fp32-MFMA kernels of csrc/te_linear.hip.  With x6 the line also carries the "
                          "fp32-MFMA throughput of the same workload from a second timed run (config.fp32_mfma_*)")
+    ap.add_argument("--x6-gemm", choices=["auto", "all", "off"], default="all",
+                    help="with --producers fused: which forward / input-gradient products of the Linear layers run on the "
+                         "split-operand bf16 kernel (te_gemm_x6_f32) instead of the stock fp32 GEMM: all (default; 73.3 vs "
+                         "78.9 ms per ViT-B step), auto = only where the operand is narrow and the output wide "
+                         "(ops.gemm_x6_wanted), off; the fp32-MFMA comparison run of the line always uses the stock GEMMs")
     ap.add_argument("--x6-tile", choices=["auto", "128", "256"], default="auto",
                     help="tile geometry of the x6 Linear kernels (measurement knob: the maps do not depend on it)")
     ap.add_argument("--producers", choices=["stock", "fused"], default="fused",
@@ -508,6 +513,7 @@ def main():
         tuned = te.enable_tuned_gemms(os.path.join(ROOT, "gpurun_out", f"tunableop_gfx950_rank{rank}.csv"), tune=True)
     if args.producers == "fused":
         ops.USE_FUSED_PRODUCERS = True
+    ops.X6_GEMM = args.x6_gemm
     ops.USE_LINEAR_X6 = args.linear == "x6"
     ops.X6_TILE = {"auto": 0, "128": 1, "256": 2}[args.x6_tile]
 
@@ -615,6 +621,7 @@ def main():
     if args.linear == "x6" and world == 1:
         lane_graphs = None
         ops.USE_LINEAR_X6 = False
+        ops.X6_GEMM = "off"          # the comparison run executes no bf16 MFMA at all: rules AND layer products on fp32 MFMAs
         try:
             g2 = None
             if used_graph:
@@ -631,12 +638,14 @@ def main():
             assert torch.isfinite(m2).all()
             fp32_cmp = {"fp32_mfma_maps_per_s" if wl.noun == "maps" else "fp32_mfma_sequences_per_s": B * args.steps / e2,
                         "fp32_mfma_ms_per_step": e2 / args.steps * 1e3,
-                        "fp32_mfma_note": "the same step with the Linear rules on the fp32-MFMA kernels (te_linear.hip), one "
+                        "fp32_mfma_note": "the same step with the Linear rules on the fp32-MFMA kernels (te_linear.hip) and the "
+                                          "layers' own products on the stock fp32 GEMMs (no bf16 MFMA anywhere), one "
                                           "graph replayed step after step; second timed run of this process"}
             log(f"fp32-MFMA comparison run: {e2 / args.steps * 1e3:.2f} ms/step")
             del g2
         finally:
             ops.USE_LINEAR_X6 = True
+            ops.X6_GEMM = args.x6_gemm
 
     if rank == 0:
         value = world * B * args.steps / elapsed
@@ -667,6 +676,12 @@ def main():
                                                 "PyTorch TunableOp, tuned in this run" if tuned else "PyTorch default"),
                        "linear_relprop": ("x6: bf16 MFMAs on three-way split fp32 operands, six partial products, fp32 "
                                           "accumulation" if args.linear == "x6" else "fp32 MFMA"),
+                       "linear_forward_backward": (("stock fp32 GEMMs, except on the x6 kernel (te_gemm_x6_f32): "
+                                                    + {"auto": "forward products and input gradients with K <= 1024 and "
+                                                               "M >= 2 K (qkv / fc1 forward, fc2 input gradient)",
+                                                       "all": "every supported product"}[args.x6_gemm])
+                                                   if args.producers == "fused" and args.x6_gemm != "off"
+                                                   else "stock fp32 GEMMs"),
                        **fp32_cmp,
                        "hip_graph": used_graph, "parallelism": f"dp{world} (independent samples, one "
                                                                       f"all_gather of the maps)"},

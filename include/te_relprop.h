@@ -310,6 +310,11 @@ int te_linear_x6_split_matrix_f32(const float* A, int64_t rows, int64_t K, int t
                                   size_t planes_bytes, te_stream_t stream);
 int te_gemm_x6_f32(const float* X, const void* x_planes, const void* w_planes, const float* bias, float* out,
                    int64_t T, int64_t K, int64_t M, void* ws, size_t ws_bytes, te_stream_t stream);
+/* One pass over a row-major A [rows, K]: its signed planes (the x_planes of te_gemm_x6_f32) AND the planes of |A| (the
+ * x_planes of te_linear_relprop_x6_f32 for the same layer input: layers_ours.py:215 clamps / pairs X by sign, the rule's Z
+ * is |X| |W|^T).  Both buffers te_linear_x6_planes_bytes(rows, K) bytes; planes_bytes = the size of each. */
+int te_linear_x6_split_dual_f32(const float* A, int64_t rows, int64_t K, void* planes, void* planes_abs,
+                                size_t planes_bytes, te_stream_t stream);
 
 /* ---- producers of the cached tensors ----------------------------------------------------
  * The attention block of baselines/ViT/ViT_LRP.py:132-152 (and its gradient, the tensor save_attn_gradients receives,

@@ -165,6 +165,57 @@ def test_linear_producer_x6_gemm(T, K, M):
     assert torch.equal(ops.gemm_x6(x[7:300].contiguous(), ops.x6_matrix_planes(W, False, cache), b, M), y[7:300])
 
 
+@pytest.mark.parametrize("T,K", [(788, 768), (300, 3072), (70, 128)])
+def test_x6_split_dual_planes(T, K):
+    """te_linear_x6_split_dual_f32: one pass, the signed planes of X and the planes of |X| -- bit for bit what the two
+    single-purpose split kernels write (zeros, negative zeros and tiny values included)."""
+    from transformer_explainability_amd import _lib
+    d = dev()
+    lib = _lib.load()
+    x = rnd((T, K), 97).to(d)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1.0, -1.0, 3.0e38, -3.0e38], device=d)
+    x[1] = -x[1].abs()
+    nb = lib.te_linear_x6_planes_bytes(T, K)
+    s = torch.cuda.current_stream().cuda_stream
+    bufs = [torch.zeros(nb, dtype=torch.uint8, device=d) for _ in range(4)]
+    _lib.check(lib.te_linear_x6_split_dual_f32(x.data_ptr(), T, K, bufs[0].data_ptr(), bufs[1].data_ptr(), nb, s), "dual")
+    _lib.check(lib.te_linear_x6_split_matrix_f32(x.data_ptr(), T, K, 0, bufs[2].data_ptr(), nb, s), "signed")
+    _lib.check(lib.te_linear_x6_split_abs_f32(x.data_ptr(), T, K, bufs[3].data_ptr(), nb, s), "abs")
+    torch.cuda.synchronize()
+    assert torch.equal(bufs[0], bufs[2])
+    assert torch.equal(bufs[1], bufs[3])
+
+
+def test_linear_rule_reuses_forward_planes():
+    """A Linear layer whose forward product ran on te_gemm_x6_f32 leaves the planes of |X| for its relprop rule
+    (ops.gemm_x6 keep_abs -> ops.linear_relprop): the rule's result is bitwise the one with its own split pass, and a
+    changed or different input makes the rule split again."""
+    from transformer_explainability_amd import ops, rules
+    d = dev()
+    lin = rules.Linear(768, 2304).to(d).eval()
+    x = rnd((2, 197, 768), 98).to(d)
+    R = rnd((2, 197, 2304), 99, 1e-3).to(d)
+    was = (ops.USE_FUSED_PRODUCERS, ops.X6_GEMM)
+    ops.USE_FUSED_PRODUCERS, ops.X6_GEMM = True, "all"
+    try:
+        lin(x)
+        cache = rules.x6_cache(lin)
+        assert "x_abs_planes" in cache and cache["x_abs_planes"][0][0] == x.data_ptr()
+        with_planes = lin.relprop(R, 1.0)
+        kept = cache.pop("x_abs_planes")
+        own_split = lin.relprop(R, 1.0)
+        assert torch.equal(with_planes, own_split)
+        cache["x_abs_planes"] = kept
+        x.mul_(1.0)                                  # version bump: the planes no longer describe self.X
+        assert ops._x_abs_key(lin.X, 394, 768) != kept[0]
+        assert torch.equal(lin.relprop(R, 1.0), own_split)
+        ops.X6_GEMM = "off"
+        lin(x)                                       # stock forward: the stale planes are dropped
+        assert "x_abs_planes" not in cache
+    finally:
+        ops.USE_FUSED_PRODUCERS, ops.X6_GEMM = was
+
+
 def test_linear_layer_on_producers():
     """rules.Linear.forward / backward through autograd with ops.USE_FUSED_PRODUCERS: same values and input gradient as the
     stock layer to fp32 rounding; the stock path below 256 rows and for shapes the kernels do not tile."""
@@ -175,8 +226,8 @@ def test_linear_layer_on_producers():
     g = rnd((4, 197, 3072), 96).to(d)
     y0 = lin(x)
     (dx0,) = torch.autograd.grad(y0, x, g)
-    was = ops.USE_X6_GEMM
-    ops.USE_FUSED_PRODUCERS = ops.USE_X6_GEMM = True
+    was = ops.X6_GEMM
+    ops.USE_FUSED_PRODUCERS, ops.X6_GEMM = True, "all"
     try:
         y1 = lin(x)
         assert "x6_gemm_planes" in rules.x6_cache(lin)
@@ -186,9 +237,19 @@ def test_linear_layer_on_producers():
         assert lin.Y is y1 and lin.X.shape == x.shape
         small = lin(x[:1])                       # 197 rows: stock kernels
         assert torch.equal(small, torch.nn.functional.linear(x[:1], lin.weight, lin.bias))
+        # per-direction policy (ops.gemm_x6_wanted): 768 -> 3072 has a narrow operand forward (x6) and a wide one backward (stock)
+        from transformer_explainability_amd import producers
+        ops.X6_GEMM = "auto"
+        assert producers.linear_plan(x, lin) == (True, False)
+        y2 = lin(x)
+        (dx2,) = torch.autograd.grad(y2, x, g)
+        assert torch.equal(y2, y1)
+        check("producer.linear.layer.dx_auto", dx2, dx0, 2e-6)
+        ops.X6_GEMM = "off"
+        assert producers.linear_plan(x, lin) == (False, False)
     finally:
         ops.USE_FUSED_PRODUCERS = False
-        ops.USE_X6_GEMM = was
+        ops.X6_GEMM = was
 
 
 @pytest.fixture()

@@ -69,6 +69,7 @@ SIGNATURES = {
     "te_gemm_x6_supported": (_I, [_I64, _I64, _I64]),
     "te_gemm_x6_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_linear_x6_split_matrix_f32": (_I, [_P, _I64, _I64, _I, _P, _SZ, _P]),
+    "te_linear_x6_split_dual_f32": (_I, [_P, _I64, _I64, _P, _P, _SZ, _P]),
     "te_gemm_x6_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
     "te_layernorm_supported": (_I, [_I64]),
     "te_layernorm_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),

@@ -93,9 +93,13 @@ __device__ __forceinline__ float apply_op(float x) {
 // writes 512 contiguous bytes per store.  TRANSPOSE: element (r, k) is src[k * R + r] (W^T operands of the C-pass);
 // the destination then is the P6 layout with `sign` selecting the W+ / W- half.
 // ------------------------------------------------------------------------------------------------
+// dst_abs (optional, OP_ID only): the planes of |src| as well, from the same pass -- the three planes of |x| are the planes
+// of x times sign(x) exactly (bf16 rounding is sign-symmetric and every residual negates with x), and sign(x) is the
+// sign bit of plane 0: clear it there, flip the low planes' sign bits where it was set.
 template <int OP, bool TRANSPOSE>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
-                                                    int64_t R, int64_t K, int group, int sign) {
+                                                    int64_t R, int64_t K, int group, int sign,
+                                                    unsigned char* __restrict__ dst_abs = nullptr) {
   const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int64_t rb = blockIdx.x;
   const int64_t ks = (int64_t)blockIdx.y * 8 + sl;
@@ -133,6 +137,27 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
       for (int e = 0; e < 4; ++e) w[e] = p[4 * kh + e][q];
       *reinterpret_cast<u32x4*>(d + q * kFrag + kh * 512) = w;
     }
+  if constexpr (OP == OP_ID) {
+    if (dst_abs) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned m = p[e][0] & 0x80008000u;
+        p[e][0] &= 0x7fff7fffu;
+        p[e][1] ^= m;
+        p[e][2] ^= m;
+      }
+      unsigned char* da = dst_abs + ((rb * nks + ks) * 3) * kFrag + r * 16;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          u32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = p[4 * kh + e][q];
+          *reinterpret_cast<u32x4*>(da + q * kFrag + kh * 512) = w;
+        }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void zero_words_kernel(u32x4* __restrict__ p) {
@@ -772,6 +797,20 @@ extern "C" int te_linear_x6_split_matrix_f32(const float* A, int64_t rows, int64
     split_kernel<OP_ID, true><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(A, (unsigned char*)planes, rows, K, 3, 0);
   else
     split_kernel<OP_ID, false><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(A, (unsigned char*)planes, rows, K, 3, 0);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// planes of A [rows, K] AND of |A| from one pass over A (the forward product of a Linear layer wants the first, its
+// relprop rule the second: te_linear_relprop_x6_f32's x_planes)
+extern "C" int te_linear_x6_split_dual_f32(const float* A, int64_t rows, int64_t K, void* planes, void* planes_abs,
+                                           size_t planes_bytes_, te_stream_t stream_) {
+  if (!A || !planes || !planes_abs || rows < 1) return TE_ERR_INVALID_ARG;
+  if (K < 16 || K % 16 || !te_aligned16(A) || rows > ((int64_t)1 << 26)) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes) || !te_aligned16(planes_abs)) return TE_ERR_WORKSPACE;
+  const dim3 grid((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8));
+  split_kernel<OP_ID, false><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(A, (unsigned char*)planes, rows, K, 3, 0,
+                                                                          (unsigned char*)planes_abs);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }

@@ -143,10 +143,23 @@ def x6_weight_planes(W: Tensor, cache: Optional[dict] = None) -> Tensor:
 
 
 # The forward output and the input gradient of a Linear layer on the x6 kernels (te_gemm_x6_f32) under
-# ops.USE_FUSED_PRODUCERS.  OPT-IN (TE_X6_GEMM=1): measured on the MI355X the tuned stock fp32 GEMMs (TunableOp: 117-148 TF)
-# still win by 2 ms per ViT-B/16 batch-64 step -- each product here pays a split pass over its activation operand first
-# (DESIGN.md section 6); the default stays rocBLAS / hipBLASLt.
-USE_X6_GEMM = os.environ.get("TE_X6_GEMM", "0") not in ("", "0")
+# ops.USE_FUSED_PRODUCERS, PER DIRECTION.  Measured on the MI355X, ViT-B/16 batch 64 (profiles/r03_x6_gemm_study.log,
+# profiles/r03_x6_gemm_step_ab.log): the x6 product runs at 125-171 TF fp32-equivalent against 110-120 TF (default) /
+# 117-148 TF (TunableOp) for the stock fp32 GEMM, but pays a split pass over its activation operand first (6 B written
+# per element: 16 us for K = 768, 85 us for K = 3072 at T = 12 608).  In the step, one trip, A B A B: every supported
+# product on x6 73.3 ms, only the narrow-operand ones (K <= 1024, M >= 2 K: qkv / fc1 forward, fc2 input gradient)
+# 74.6-74.8 ms, none 78.9 ms.  X6_GEMM = "all" (default) | "auto" (the narrow-operand policy) | "off"; TE_X6_GEMM=0 / 1 =
+# off / all.  Both kernels are fp32 GEMMs to fp32 rounding (tests/test_gpu_producers.py).
+X6_GEMM = {"": "all", "1": "all", "0": "off"}.get(os.environ.get("TE_X6_GEMM", "all"), os.environ.get("TE_X6_GEMM", "all"))
+if X6_GEMM not in ("all", "auto", "off"):
+    raise ValueError(f"TE_X6_GEMM={X6_GEMM!r}: expected all / auto / off (or 1 / 0)")
+
+
+def gemm_x6_wanted(T: int, K: int, M: int) -> bool:
+    """Should out [T, M] = X [T, K] . W^T run on te_gemm_x6_f32 (policy above)?"""
+    if X6_GEMM == "off" or T < 256 or not gemm_x6_supported(T, K, M):
+        return False
+    return X6_GEMM == "all" or (K <= 1024 and M >= 2 * K)
 
 
 def x6_matrix_planes(W: Tensor, transposed: bool, cache: Optional[dict] = None) -> Tensor:
@@ -174,8 +187,15 @@ def gemm_x6_supported(T: int, K: int, M: int) -> bool:
     return bool(_lib.load().te_gemm_x6_supported(int(T), int(K), int(M)))
 
 
-def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_name: str = "gemm_x6") -> Tensor:
-    """out [..., M] = X [..., K] . W^T + bias with W as signed planes of an [M, K] matrix (x6_matrix_planes)."""
+def _x_abs_key(X: Tensor, T: int, K: int):
+    return (X.data_ptr(), X._version, T, K, str(X.device))
+
+
+def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_name: str = "gemm_x6",
+            keep_abs: Optional[dict] = None) -> Tensor:
+    """out [..., M] = X [..., K] . W^T + bias with W as signed planes of an [M, K] matrix (x6_matrix_planes).
+    keep_abs: the layer's cache dict -- the split pass then also writes the planes of |X| (te_linear_x6_split_dual_f32) and
+    leaves them there for the layer's relprop rule (linear_relprop: the rule's own split pass over X disappears)."""
     K = X.shape[-1]
     lead = X.shape[:-1]
     Xc = _c(X).reshape(-1, K)
@@ -185,7 +205,14 @@ def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_n
     with _on_device(Xc) as lib:
         ws = _ws(lib.te_gemm_x6_workspace_bytes(T, K, M), Xc)
         with _timed(timer_name, 12.0 * T * K * M, 10.0 * T * K + 6.0 * K * M + 4.0 * T * M):
-            _lib.check(lib.te_gemm_x6_f32(_ptr(Xc), None, _ptr(w_planes), _ptr(bc), _ptr(out), T, K, M, _ptr(ws),
+            xs = None
+            if keep_abs is not None and USE_LINEAR_X6 and lib.te_linear_relprop_x6_supported(T, K, M):
+                nb = lib.te_linear_x6_planes_bytes(T, K)
+                xs, xa = _ws(nb, Xc), _ws(nb, Xc)
+                _lib.check(lib.te_linear_x6_split_dual_f32(_ptr(Xc), T, K, _ptr(xs), _ptr(xa), nb, _stream(Xc)),
+                           "te_linear_x6_split_dual_f32")
+                keep_abs["x_abs_planes"] = (_x_abs_key(X, T, K), xa)
+            _lib.check(lib.te_gemm_x6_f32(_ptr(Xc), _ptr(xs), _ptr(w_planes), _ptr(bc), _ptr(out), T, K, M, _ptr(ws),
                                           ws.numel(), _stream(Xc)), "te_gemm_x6_f32")
     return out.reshape(*lead, M)
 
@@ -222,12 +249,17 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
     if (fwd and USE_LINEAR_X6 and Yc.data_ptr() % 16 == 0 and (bc is None or bc.data_ptr() % 16 == 0)
             and _lib.load().te_linear_relprop_x6_supported(T, in_f, out_f)):
         planes = x6_weight_planes(Wc, cache)
+        xa = None       # the planes of |X| the layer's own forward product left behind (gemm_x6 keep_abs), if X is that tensor
+        if cache is not None:
+            hit = cache.get("x_abs_planes")
+            if hit is not None and hit[0] == _x_abs_key(X, T, in_f):
+                xa = hit[1]
         with _on_device(Xc) as lib:
             ws = _ws(lib.te_linear_relprop_x6_workspace_bytes(T, in_f, out_f), Xc)
 
             def call(flags):
                 _lib.check(lib.te_linear_relprop_x6_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc), _ptr(planes),
-                                                        None, _ptr(Yc), _ptr(bc), _ptr(out), T, in_f, out_f,
+                                                        _ptr(xa), _ptr(Yc), _ptr(bc), _ptr(out), T, in_f, out_f,
                                                         X6_TILE | flags, _ptr(ws), ws.numel(), _stream(Xc)),
                            "te_linear_relprop_x6_f32")
             if KERNEL_TIMER is None:

@@ -72,30 +72,38 @@ class _Gelu(torch.autograd.Function):
 
 
 class _Linear(torch.autograd.Function):
-    """nn.Linear (modules/layers_ours.py:207: ``class Linear(nn.Linear, RelProp)``) on the split-operand bf16 kernels of
-    csrc/te_linear_x6.hip: y = x W^T + b and, backward, d_x = d_y W -- each fp32 operand as three bf16 planes, six
-    partial products, fp32 accumulation (fp32-class accuracy: tests/test_gpu_producers.py).  No weight / bias gradient
-    (the explanation differentiates w.r.t. activations only; eval mode only, like the LayerNorm producer)."""
+    """nn.Linear (modules/layers_ours.py:207: ``class Linear(nn.Linear, RelProp)``) with y = x W^T + b and / or, backward,
+    d_x = d_y W on the split-operand bf16 kernels of csrc/te_linear_x6.hip -- each fp32 operand as three bf16 planes, six
+    partial products, fp32 accumulation (fp32-class accuracy: tests/test_gpu_producers.py); the direction that is not
+    worth an operand split (ops.gemm_x6_wanted) stays on the stock fp32 GEMM.  No weight / bias gradient (the explanation
+    differentiates w.r.t. activations only; eval mode only, like the LayerNorm producer)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
-        ctx.weight, ctx.cache = weight, cache
-        return ops.gemm_x6(x, ops.x6_matrix_planes(weight, False, cache), bias, weight.shape[0], "linear_forward_x6")
+    def forward(ctx, x, weight, bias, cache, fwd_x6, bwd_x6):
+        ctx.weight, ctx.cache, ctx.bwd_x6 = weight, cache, bwd_x6
+        if fwd_x6:
+            return ops.gemm_x6(x, ops.x6_matrix_planes(weight, False, cache), bias, weight.shape[0], "linear_forward_x6",
+                               keep_abs=cache)
+        return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         w = ctx.weight
-        return ops.gemm_x6(dy, ops.x6_matrix_planes(w, True, ctx.cache), None, w.shape[1], "linear_backward_x6"), None, None, None
+        if ctx.bwd_x6:
+            dx = ops.gemm_x6(dy, ops.x6_matrix_planes(w, True, ctx.cache), None, w.shape[1], "linear_backward_x6")
+        else:
+            dx = torch.matmul(dy, w)
+        return dx, None, None, None, None, None
 
 
-def linear_usable(x: torch.Tensor, lin) -> bool:
-    if not (ops.USE_FUSED_PRODUCERS and ops.USE_X6_GEMM and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
-            and not lin.training and x.dim() >= 2):
-        return False
+def linear_plan(x: torch.Tensor, lin):
+    """(forward on x6?, input gradient on x6?) for this call of an nn.Linear; (False, False) = leave the layer alone."""
+    if not (ops.USE_FUSED_PRODUCERS and ops.X6_GEMM != "off" and torch.is_tensor(x) and x.is_cuda
+            and x.dtype == torch.float32 and not lin.training and x.dim() >= 2):
+        return False, False
     out_f, in_f = lin.weight.shape
     T = x.numel() // in_f
-    # both directions on the x6 kernels, or neither (a stock forward with an x6 backward would mix two roundings)
-    return T >= 256 and ops.gemm_x6_supported(T, in_f, out_f) and ops.gemm_x6_supported(T, out_f, in_f)
+    return ops.gemm_x6_wanted(T, in_f, out_f), ops.gemm_x6_wanted(T, out_f, in_f)
 
 
 # The parameters enter the producer nodes DETACHED: these nodes produce the input gradient only, and autograd is told so
@@ -105,8 +113,8 @@ def _d(t):
     return None if t is None else t.detach()
 
 
-def linear(x, lin, cache):
-    return _Linear.apply(x, _d(lin.weight), _d(lin.bias), cache)
+def linear(x, lin, cache, plan):
+    return _Linear.apply(x, _d(lin.weight), _d(lin.bias), cache, plan[0], plan[1])
 
 
 def layer_norm(x, norm):

@@ -137,9 +137,12 @@ class Linear(nn.Linear, RelProp):
     """layers_ours.py:207-230 / layers_lrp.py:188-211 -> te_linear_relprop_f32."""
 
     def forward(self, x):
-        from . import producers                      # 8f.1: forward / input gradient on te_gemm_x6_f32
-        if producers.linear_usable(x, self):
-            return producers.linear(x, self, x6_cache(self))
+        from . import producers                      # 8f.1: forward and / or input gradient on te_gemm_x6_f32
+        plan = producers.linear_plan(x, self)
+        if not plan[0]:
+            x6_cache(self).pop("x_abs_planes", None)      # no x6 forward product of THIS input: nothing for the rule to reuse
+        if plan[0] or plan[1]:
+            return producers.linear(x, self, x6_cache(self), plan)
         return super().forward(x)
 
     def relprop(self, R, alpha):
