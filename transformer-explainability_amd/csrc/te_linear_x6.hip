@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
       for (int e = 0; e < 8; ++e) {
         const unsigned m = p[e][0] & 0x80008000u;
         p[e][0] &= 0x7fff7fffu;
-        p[e][1] ^= m;
-        p[e][2] ^= m;
+        // a zero residual is +0 whatever the sign of x (x - x = +0): flip the sign bit of non-zero halves only, so that
+        // the planes are bit for bit those of split3(|x|).  (h & 0x7fff) + 0x7fff has bit 15 set iff the half is non-zero.
+        p[e][1] ^= m & (((p[e][1] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u);
+        p[e][2] ^= m & (((p[e][2] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u);
       }
       unsigned char* da = dst_abs + ((rb * nks + ks) * 3) * kFrag + r * 16;
 #pragma unroll

@@ -187,6 +187,9 @@ def gemm_x6_supported(T: int, K: int, M: int) -> bool:
     return bool(_lib.load().te_gemm_x6_supported(int(T), int(K), int(M)))
 
 
+X6_KEEP_ABS = os.environ.get("TE_X6_KEEP_ABS", "1") not in ("", "0")     # measurement switch for the plane reuse below
+
+
 def _x_abs_key(X: Tensor, T: int, K: int):
     return (X.data_ptr(), X._version, T, K, str(X.device))
 
@@ -194,7 +197,7 @@ def _x_abs_key(X: Tensor, T: int, K: int):
 def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_name: str = "gemm_x6",
             keep_abs: Optional[dict] = None) -> Tensor:
     """out [..., M] = X [..., K] . W^T + bias with W as signed planes of an [M, K] matrix (x6_matrix_planes).
-    keep_abs: the layer's cache dict -- the split pass then also writes the planes of |X| (te_linear_x6_split_dual_f32) and
+    keep_abs: the layer's cache dict -- the split pass then also writes the planes of |X| (bit for bit those of a split of |X|) (te_linear_x6_split_dual_f32) and
     leaves them there for the layer's relprop rule (linear_relprop: the rule's own split pass over X disappears)."""
     K = X.shape[-1]
     lead = X.shape[:-1]
@@ -206,7 +209,8 @@ def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_n
         ws = _ws(lib.te_gemm_x6_workspace_bytes(T, K, M), Xc)
         with _timed(timer_name, 12.0 * T * K * M, 10.0 * T * K + 6.0 * K * M + 4.0 * T * M):
             xs = None
-            if keep_abs is not None and USE_LINEAR_X6 and lib.te_linear_relprop_x6_supported(T, K, M):
+            if (keep_abs is not None and USE_LINEAR_X6 and X6_KEEP_ABS
+                    and lib.te_linear_relprop_x6_supported(T, K, M)):
                 nb = lib.te_linear_x6_planes_bytes(T, K)
                 xs, xa = _ws(nb, Xc), _ws(nb, Xc)
                 _lib.check(lib.te_linear_x6_split_dual_f32(_ptr(Xc), T, K, _ptr(xs), _ptr(xa), nb, _stream(Xc)),
