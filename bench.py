@@ -714,7 +714,7 @@ def main():
                         "(class-token path of the last block) are excluded from the table's averages (the headline block "
                         "above averages every launch, like rocprofv3's kernel-stats row)")
         x6c = timer.summary("linear_x6_cpass", 0.0)
-        x6z = timer.summary("linear_x6_zpass", 0.0)
+        x6z = timer.summary("linear_x6_zpass")      # (full-size launches; the table's row)
         cp = timer.summary("linear_cpass", 0.0)
         zp = timer.summary("linear_zpass_fwd", 0.0) or timer.summary("linear_zpass", 0.0)
         if x6c:

@@ -83,6 +83,30 @@ def test_sweep_sharded_equals_single(tmp_path):
             assert x.shape == y.shape and float((x.float() - y.float()).abs().max()) <= 2e-4
 
 
+def test_hdf5_backend_round_trip(tmp_path):
+    """The reference's own results.hdf5 (generate_visualizations.py:29-44 writes it, dataset/expl_hdf5.py:8-31 reads it):
+    needs h5py, which the build image does not ship -- where it is missing this test SKIPS with that reason (so the
+    backend shows up as untested in the report instead of silently passing), and the store refuses the backend loudly."""
+    from transformer_explainability_amd.sweep import ImagenetResults, ResultsStore, _have_h5py
+    if not _have_h5py():
+        with pytest.raises(ImportError):
+            ResultsStore(str(tmp_path), 2, (3, 4, 4), (1, 4, 4), backend="hdf5")
+        pytest.skip("h5py is not importable in this image: the hdf5 result-store backend is UNTESTED here "
+                    "(the sharded .npy backend is what the sweep tests exercise)")
+    import h5py
+    from oracle_backend import oracle_ops
+    with oracle_ops():
+        ds = _sweep("transformer_attribution", torch.device("cpu"), str(tmp_path), backend="hdf5")
+        _check_store(ds, str(tmp_path), "transformer_attribution", torch.device("cpu"))
+    with h5py.File(str(tmp_path / "results.hdf5"), "r") as f:          # the layout the reference's reader expects
+        assert set(f.keys()) == {"vis", "image", "target"}
+        assert f["vis"].shape == (7, 1, 32, 32) and f["image"].shape == (7, 3, 32, 32) and f["target"].shape == (7,)
+        assert f["vis"].dtype == np.float32 and f["target"].dtype == np.int32 and f["vis"].compression == "gzip"
+    assert len(ImagenetResults(str(tmp_path))) == 7
+    with pytest.raises(ValueError):                                    # one results.hdf5 = one rank
+        ResultsStore(str(tmp_path / "x"), 7, (3, 32, 32), (1, 32, 32), 0, 3, backend="hdf5")
+
+
 def test_store_guards(tmp_path):
     from transformer_explainability_amd.sweep import ImagenetResults, ResultsStore, SaliencySweep
     with pytest.raises(ValueError):

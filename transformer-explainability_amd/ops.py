@@ -272,7 +272,10 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
                 # bench.py roofline probe: the three phases one by one so that each is bracketed by HIP events.
                 # flops = the bf16 MFMA work EXECUTED (six partial products per fp32 product); bytes = algorithmic
                 gemm = 2.0 * T * in_f * out_f
-                with _timed("linear_x6_split", 0.0, 10.0 * T * in_f):
+                if xa is None:
+                    with _timed("linear_x6_split", 0.0, 10.0 * T * in_f):
+                        call(TE_X6_PHASE_SPLIT)
+                else:       # the planes came with the forward product: this phase only resets the hand-over flags
                     call(TE_X6_PHASE_SPLIT)
                 with _timed("linear_x6_zpass", 6.0 * gemm, 6.0 * (T * in_f + in_f * out_f + T * out_f) + 8.0 * T * out_f):
                     call(TE_X6_PHASE_Z)
