@@ -155,8 +155,11 @@ def test_linear_from_forward_output(T, in_f, out_f):
     check(f"linear_fwd_nobias({T},{in_f},{out_f})", got_nb, ref, 2e-5)
 
 
+# every Linear shape of the three bench configurations (ViT-B/16: 768 -> 2304 / 768 / 3072, 3072 -> 768; ViT-L/16:
+# 1024 -> 3072 / 1024 / 4096, 4096 -> 1024; BERT-base: 768 -> 768 / 3072, 3072 -> 768) + two small odd ones
 @pytest.mark.parametrize("T,in_f,out_f", [(394, 768, 3072), (140, 256, 384), (130, 3072, 768), (257, 128, 128),
-                                          (1576, 768, 768), (600, 1024, 1024)])
+                                          (1576, 768, 768), (600, 1024, 1024), (394, 768, 2304), (300, 1024, 3072),
+                                          (300, 1024, 4096), (300, 4096, 1024)])
 def test_linear_x6_split_operand_path(T, in_f, out_f):
     """DEFAULT path since round 3 (csrc/te_linear_x6.hip): the rule's three products on bf16 MFMAs with every fp32
     operand split into three bf16 parts (six partial products kept), persistent sequential stream-K schedule.  Must agree

@@ -280,6 +280,31 @@ def test_producer_switch_is_inert_off_the_gpu(tiny_vit, golden_vit_tiny):
         ops.USE_FUSED_PRODUCERS = False
 
 
+def test_x6_gemm_direction_policy():
+    """ops.gemm_x6_wanted / producers.linear_plan: which products of a Linear layer go to te_gemm_x6_f32 (host logic only:
+    the C ABI answers the shape question without a GPU).  all = every supported product of >= 256 rows; auto = narrow
+    operand, wide output; off = none; host tensors and training-mode layers are never planned."""
+    from transformer_explainability_amd import ops, producers, rules
+    was = (ops.USE_FUSED_PRODUCERS, ops.X6_GEMM)
+    try:
+        ops.X6_GEMM = "all"
+        assert ops.gemm_x6_wanted(12608, 768, 2304) and ops.gemm_x6_wanted(12608, 3072, 768)
+        assert not ops.gemm_x6_wanted(197, 768, 2304)            # below 256 rows: the stock GEMM
+        assert not ops.gemm_x6_wanted(12608, 768, 1000)          # the head: 1000 classes are not a multiple of 128
+        ops.X6_GEMM = "auto"
+        assert ops.gemm_x6_wanted(12608, 768, 2304) and ops.gemm_x6_wanted(12608, 768, 3072)
+        assert not ops.gemm_x6_wanted(12608, 768, 768) and not ops.gemm_x6_wanted(12608, 3072, 768)
+        ops.X6_GEMM = "off"
+        assert not ops.gemm_x6_wanted(12608, 768, 2304)
+        ops.USE_FUSED_PRODUCERS, ops.X6_GEMM = True, "all"
+        lin = rules.Linear(768, 2304).eval()
+        assert producers.linear_plan(torch.zeros(2, 197, 768), lin) == (False, False)        # host tensor
+        y = lin(torch.zeros(2, 197, 768))                                                   # ... and the stock forward runs
+        assert y.shape == (2, 197, 2304) and "x_abs_planes" not in rules.x6_cache(lin)
+    finally:
+        ops.USE_FUSED_PRODUCERS, ops.X6_GEMM = was
+
+
 def test_bench_refuses_fewer_gpus_than_ranks():
     """`python bench.py --gpus 2` on a host with fewer than 2 GPUs must fail loudly -- never print an n_gpus: 1 line."""
     import os
