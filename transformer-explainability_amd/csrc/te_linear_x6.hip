@@ -33,6 +33,12 @@
 //                   falls: a batch equals its samples run one by one, bit for bit, and no tile quantisation is left (at
 //                   ViT-B batch 64 the 256-wide tiles of the eight launches of a block fill 59-94 % of whole rounds).
 //                   Waits only ever go to a LOWER workgroup index of the same XCD slot order.
+//                   Where the last round of whole tiles is nearly full (ceil(r) <= 1.15 r, r = tiles per workgroup) the
+//                   ranges are cut at tile boundaries instead (launch_x6): the workgroups of an XCD then walk k in
+//                   lock-step on shared operand panels and a K16 step takes 1.9 us instead of 2.1-2.6 us.
+//   plain GEMM      MODE_G: out = X W^T + b on the same loop (te_gemm_x6_f32: the Linear layers' own forward product and
+//                   input gradient); te_linear_x6_split_dual_f32 writes the planes of a layer input and
+//                   of its absolute value in one pass, so the rule reuses what the forward product split.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
