@@ -165,10 +165,26 @@ def test_linear_producer_x6_gemm(T, K, M):
     assert torch.equal(ops.gemm_x6(x[7:300].contiguous(), ops.x6_matrix_planes(W, False, cache), b, M), y[7:300])
 
 
-@pytest.mark.parametrize("T,K", [(788, 768), (300, 3072), (70, 128)])
+def _reference_planes(x):
+    """The P3 plane layout of csrc/te_linear_x6.hip written with torch: p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)
+    (round to nearest even, exact residuals), stored [rows / 32][K / 16][plane 3][k half 2][row 32][8 bf16]."""
+    T, K = x.shape
+    Tp = (T + 31) // 32 * 32
+    xp = torch.zeros(Tp, K, dtype=torch.float32, device=x.device)
+    xp[:T] = x
+    p0 = xp.bfloat16()
+    r1 = xp - p0.float()
+    p1 = r1.bfloat16()
+    p2 = (r1 - p1.float()).bfloat16()
+    pl = torch.stack([p0, p1, p2], 0).view(3, Tp // 32, 32, K // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+    return pl.view(torch.uint8).flatten()
+
+
+@pytest.mark.parametrize("T,K", [(788, 768), (300, 3072), (70, 128), (33, 144)])
 def test_x6_split_dual_planes(T, K):
     """te_linear_x6_split_dual_f32: one pass, the signed planes of X and the planes of |X| -- bit for bit what the two
-    single-purpose split kernels write (zeros, negative zeros and tiny values included)."""
+    single-purpose split kernels write (zeros, negative zeros and tiny values included), and bit for bit the layout and
+    rounding of a torch restatement of the split (K = 144: a last group of K16 steps that is not full)."""
     from transformer_explainability_amd import _lib
     d = dev()
     lib = _lib.load()
@@ -184,6 +200,8 @@ def test_x6_split_dual_planes(T, K):
     torch.cuda.synchronize()
     assert torch.equal(bufs[0], bufs[2])
     assert torch.equal(bufs[1], bufs[3])
+    assert torch.equal(bufs[2], _reference_planes(x))
+    assert torch.equal(bufs[3], _reference_planes(x.abs()))
 
 
 def test_linear_rule_reuses_forward_planes():
