@@ -66,7 +66,7 @@ def log(msg):
 
 def _resolve(args):
     if args.overlap_backward == "auto":
-        args.overlap_backward = "on" if args.config in ("vit_b16_224", "vit_l16_384") else "off"   # (the BERT generator has no side stream)
+        args.overlap_backward = "on"
     return args
 
 
@@ -95,9 +95,9 @@ def parse_args(argv=None):
                          "attn_cam never reaches the map); off = every block, as the reference does")
     ap.add_argument("--overlap-backward", choices=["auto", "on", "off"], default="auto",
                     help="run the relprop rules on a side stream beside the attention-gradient backward pass: bitwise-equal "
-                         "maps, graph-capturable.  auto (default since round 3) = on for the ViT configurations (ViT-B/16: 851 vs "
-                         "803 maps/s under rocprofv3, one trip; ViT-L/16-384: 81.7 vs 79.1); the BERT generator has no side "
-                         "stream; the eager probe step that feeds the roofline block always runs serially")
+                         "maps, graph-capturable.  auto (default since round 3) = on (ViT-B/16: 851 vs 803 maps/s under rocprofv3, one "
+                         "trip; ViT-L/16-384: 81.7 vs 79.1; BERT-512: profiles/r03_overlap_backward_ab.log); the eager probe "
+                         "step that feeds the roofline block always runs serially")
     ap.add_argument("--inflight", type=int, default=1,
                     help="consecutive steps (batches) in flight, each on its own HIP stream (eager launches)")
     ap.add_argument("--linear", choices=["x6", "fp32"], default="x6",
@@ -323,7 +323,7 @@ class Workload:
             mask[::2, 512 - 64:] = 0       # half of the batch padded: the broadcast-mask Add rule is exercised
             self.inputs = (ids, mask.to(dev))
             self.model = model.to(dev)
-            self.gen = Generator(self.model, prune=(args.prune == "on"))
+            self.gen = Generator(self.model, prune=(args.prune == "on"), overlap_backward=(args.overlap_backward == "on"))
             self.tokens, self.out_cols, self.blocks = 512, 512, 12
             self.unit, self.noun = "sequences/s", "sequences"
             self.side = None

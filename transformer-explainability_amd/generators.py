@@ -265,9 +265,14 @@ class GraphedLRP:
 class Generator:
     """BERT_explainability/modules/BERT/ExplanationGenerator.py:20-59 (generate_LRP)."""
 
-    def __init__(self, model, prune=False):
+    def __init__(self, model, prune=False, overlap_backward=False):
         self.model = model
         self.model.eval()
+        # (extension, as LRP.overlap_backward) the relprop rules read forward caches only: run them on a side stream beside
+        # the attention-gradient backward pass; both streams join before anything reads attn_cam / the gradients.  Same
+        # kernels, same results, bit for bit.
+        self.overlap_backward = bool(overlap_backward)
+        self._relprop_stream = None
         # (extension, off by default) generate_LRP reads attn_cam / attention gradients of the layers >= start_layer
         # only (ExplanationGenerator.py:47-57) -- with the reference's default start_layer = 11 that is the LAST layer
         # alone, yet relevance and gradients are propagated through all twelve.  prune=True stops the relprop right
@@ -286,17 +291,30 @@ class Generator:
         loss = torch.sum(one_hot * output)
         layers = self.model.bert.encoder.layer
         first = lowest_layer if self.prune else 0
-        _attention_gradients(loss, [lay.attention.self for lay in list(layers)[first:]])
+        side = main = None
+        if self.overlap_backward and one_hot.is_cuda:
+            main = torch.cuda.current_stream(one_hot.device)
+            if self._relprop_stream is None:
+                self._relprop_stream = torch.cuda.Stream(device=one_hot.device)
+            side = self._relprop_stream
+            side.wait_stream(main)                  # forward caches + one-hot are complete
+        _attention_gradients(loss, [lay.attention.self for lay in list(layers)[first:]])      # main stream
         stop_at = layers[first].attention.self if self.prune else None
         if stop_at is not None:
             stop_at._stop_after_attn_cam = True
         try:
-            self.model.relprop(one_hot, alpha=1)
+            if side is not None:
+                with torch.cuda.stream(side):
+                    self.model.relprop(one_hot, alpha=1)
+            else:
+                self.model.relprop(one_hot, alpha=1)
         except StopRelprop:
             pass
         finally:
             if stop_at is not None:
                 stop_at._stop_after_attn_cam = False
+            if side is not None:
+                main.wait_stream(side)              # the tail (head-mean, rollout) reads both streams' results
         return layers
 
     def generate_LRP(self, input_ids, attention_mask, index=None, start_layer=11):
