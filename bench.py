@@ -591,10 +591,10 @@ def main():
     for k in range(args.steps):
         # with graph replay, ONE step of the timed region runs eagerly with a HIP-event pair around every C-ABI call of
         # the relprop path (events cannot be recorded inside a replayed graph); same kernels, same order, one stream
-        any_graph = graphed is not None or lane_graphs is not None
-        probe = (not any_graph and lanes is None) or (k == args.steps - 1)
+        # (eager configurations too: their other steps run as the library would -- relprop beside the backward pass, no events)
+        probe = k == args.steps - 1
         timer.enabled = probe and not args.no_roofline
-        maps = step(eager=probe and (any_graph or lanes is not None) and not args.no_roofline)
+        maps = step(eager=probe and not args.no_roofline)
     host_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (GPU still running)
     join()
     gathered = parallel.gather_maps(maps, world * B)
