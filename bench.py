@@ -613,6 +613,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert gathered.shape == (world * B, wl.out_cols) and torch.isfinite(gathered).all()
+    ops.x6_raise_if_failed(dev)      # sticky device word of every x6 launch of the run (no synchronisation inside a step)
 
     # Rounds stay comparable: with the x6 Linear rules the same workload is timed once more on the fp32-MFMA kernels of
     # csrc/te_linear.hip (own graph capture, one warm-up, the same number of steps); N = 1 only, after the timed region.
@@ -636,6 +637,7 @@ def main():
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t1
             assert torch.isfinite(m2).all()
+            ops.x6_raise_if_failed(dev)
             fp32_cmp = {"fp32_mfma_maps_per_s" if wl.noun == "maps" else "fp32_mfma_sequences_per_s": B * args.steps / e2,
                         "fp32_mfma_ms_per_step": e2 / args.steps * 1e3,
                         "fp32_mfma_note": "the same step with the Linear rules on the fp32-MFMA kernels (te_linear.hip) and the "

@@ -274,11 +274,25 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
  * workgroups that share a tile (sequential stream-K: one k-ordered chain per output wherever a tile is cut), flags.
  * flags: TE_X6_TILE_AUTO (per pass: 256 weight rows per tile / one 512-thread workgroup per CU where that gives every CU
  * a tile, else 128 rows / two 256-thread workgroups per CU; the result does not depend on the tile geometry, bit for
- * bit), TE_X6_TILE_128 / TE_X6_TILE_256 pin it.
+ * bit), TE_X6_TILE_128 / TE_X6_TILE_256 pin it; shifted left by TE_X6_TILE_Z_SHIFT / TE_X6_TILE_C_SHIFT they pin one pass.
+ * TE_X6_STAGES_2: two LDS stages instead of three in the 256-row geometry (measurement; same results).
+ *
+ * Failure is loud.  A workgroup that continues a tile another workgroup started waits for that one's accumulators for at
+ * most 250 ms.  If the wait expires it ORs 1 into *status -- a caller-owned, caller-zeroed device word that is NEVER
+ * cleared by the library (sticky across calls: read it once where the caller synchronises anyway) -- sets the error word
+ * te_linear_relprop_x6_check reads, and continues from NaN accumulators: every output of that tile is NaN (te_gemm_x6_f32,
+ * C-pass) or recomputed by the rule's exact fallback (Z-pass).  Once *status is non-zero, later waits give up at once.
+ * status = NULL: the per-call error word only.  TE_X6_TEST_DROP_HANDOVER (tests): publishers keep their flags down, so
+ * every such wait expires; TE_X6_TEST_SMALL_GRID (tests): sixteen workgroups, i.e. cut tiles on small shapes.
  * te_linear_relprop_x6_check (synchronises) returns 1 if a bounded hand-over wait of the last call expired. */
 #define TE_X6_TILE_AUTO 0
 #define TE_X6_TILE_128 1
 #define TE_X6_TILE_256 2
+#define TE_X6_STAGES_2 0x100
+#define TE_X6_TEST_DROP_HANDOVER 0x200
+#define TE_X6_TEST_SMALL_GRID 0x4000   /* tests: a persistent grid of 16 workgroups, so that small shapes get stream-K cuts */
+#define TE_X6_TILE_Z_SHIFT 10
+#define TE_X6_TILE_C_SHIFT 12
 /* optional phase mask (measurement: one phase per call on the same workspace, in this order); 0 = the whole rule */
 #define TE_X6_PHASE_SPLIT 4    /* clear the flags, |X| -> planes (unless x_planes is given) */
 #define TE_X6_PHASE_Z 8        /* S planes */
@@ -295,21 +309,23 @@ int te_linear_x6_split_abs_f32(const float* X, int64_t rows, int64_t K, void* pl
 int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_scale_stride, int64_t rows_per_sample,
                              const float* X, const float* W, const void* w_planes, const void* x_planes,
                              const float* Y, const float* bias, float* out,
-                             int64_t T, int64_t in_f, int64_t out_f, int flags, void* ws, size_t ws_bytes,
-                             te_stream_t stream);
+                             int64_t T, int64_t in_f, int64_t out_f, int flags, unsigned* status, void* ws,
+                             size_t ws_bytes, te_stream_t stream);
 int te_linear_relprop_x6_check(const void* ws, int64_t T, int64_t in_f, int64_t out_f, te_stream_t stream);
 
 /* The plain fp32 product on the same kernels (the forward output and the input gradient of a Linear layer,
  * modules/layers_ours.py:207 = nn.Linear): out [T, M] = X [T, K] . W^T + bias [M] with W given as signed P3 planes of an
  * [M, K] matrix.  te_linear_x6_split_matrix_f32 builds such planes from a row-major [rows, K] matrix (transposed = 0) or
  * from its transpose stored as [K, rows] (transposed = 1: the planes of W^T for d_x = d_y W).  M % 128 == 0, K % 16 == 0.
- * x_planes = NULL: X is split into the workspace first. */
+ * x_planes = NULL: X is split into the workspace first.  flags: TE_X6_TILE_* | TE_X6_STAGES_2 | TE_X6_TEST_DROP_HANDOVER;
+ * status: as te_linear_relprop_x6_f32. */
 int te_gemm_x6_supported(int64_t T, int64_t K, int64_t M);
 size_t te_gemm_x6_workspace_bytes(int64_t T, int64_t K, int64_t M);
 int te_linear_x6_split_matrix_f32(const float* A, int64_t rows, int64_t K, int transposed, void* planes,
                                   size_t planes_bytes, te_stream_t stream);
 int te_gemm_x6_f32(const float* X, const void* x_planes, const void* w_planes, const float* bias, float* out,
-                   int64_t T, int64_t K, int64_t M, void* ws, size_t ws_bytes, te_stream_t stream);
+                   int64_t T, int64_t K, int64_t M, int flags, unsigned* status, void* ws, size_t ws_bytes,
+                   te_stream_t stream);
 /* One pass over a row-major A [rows, K]: its signed planes (the x_planes of te_gemm_x6_f32) AND the planes of |A| (the
  * x_planes of te_linear_relprop_x6_f32 for the same layer input: layers_ours.py:215 clamps / pairs X by sign, the rule's Z
  * is |X| |W|^T).  Both buffers te_linear_x6_planes_bytes(rows, K) bytes; planes_bytes = the size of each. */

@@ -230,6 +230,151 @@ def test_linear_x6_split_operand_path(T, in_f, out_f):
         ops.X6_TILE = 0
 
 
+def _x6_operands(T, in_f, out_f, seed):
+    X, W, R = rnd((T, in_f), seed), rnd((out_f, in_f), seed + 1, 0.05), rnd((T, out_f), seed + 2, 0.01)
+    bias = rnd((out_f,), seed + 3, 0.3)
+    Xd, Wd, bd, Rd = X.to(dev()), W.to(dev()), bias.to(dev()), R.to(dev())
+    return Xd, Wd, bd, Rd, torch.nn.functional.linear(Xd, Wd, bd)
+
+
+@pytest.mark.parametrize("T,in_f,out_f", [(1100, 768, 2304), (900, 3072, 768), (700, 256, 512), (257, 128, 256)])
+def test_linear_x6_schedules_are_bitwise_equal(T, in_f, out_f):
+    """One k-ordered chain per output whatever the schedule: both tile geometries (per pass), two and three LDS stages
+    (round 4: prefetch distance 2 in the 256-row geometry), and a 16-workgroup grid that cuts nearly every tile of these
+    small shapes in two (the stream-K hand-over, which the default grid only uses at batch-64 sizes) give the same bits --
+    for the rule and for the plain product of the same kernel."""
+    from transformer_explainability_amd import ops
+    Xd, Wd, bd, Rd, Y = _x6_operands(T, in_f, out_f, 300)
+    was = ops.USE_LINEAR_X6
+    ops.USE_LINEAR_X6, ops.X6_CHECK = True, True
+    try:
+        cache = {}
+        ops.x6_raise_if_failed()
+        base = ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)
+        wp = ops.x6_matrix_planes(Wd, False, cache)
+        gbase = ops.gemm_x6(Xd, wp, bd, out_f)
+        check(f"gemm_x6_small({T},{in_f},{out_f})", gbase, Y, 1e-5)
+        for tile in (1, 2):
+            for st in (0, ops.TE_X6_STAGES_2):
+                for grid in (0, ops.TE_X6_TEST_SMALL_GRID):
+                    ops.X6_TILE, ops.X6_FLAGS = tile, st | grid
+                    got = ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)
+                    assert torch.equal(got, base), (tile, st, grid)
+                    assert torch.equal(ops.gemm_x6(Xd, wp, bd, out_f), gbase), (tile, st, grid)
+        # per-pass pins: Z on 128-row tiles, C on 256-row tiles and the other way round
+        ops.X6_TILE = 0
+        for fl in ((1 << ops.TE_X6_TILE_Z_SHIFT) | (2 << ops.TE_X6_TILE_C_SHIFT),
+                   (2 << ops.TE_X6_TILE_Z_SHIFT) | (1 << ops.TE_X6_TILE_C_SHIFT)):
+            ops.X6_FLAGS = fl | ops.TE_X6_TEST_SMALL_GRID
+            assert torch.equal(ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache), base), fl
+        ops.x6_raise_if_failed()
+    finally:
+        ops.USE_LINEAR_X6, ops.X6_CHECK, ops.X6_TILE, ops.X6_FLAGS = was, False, 0, 0
+
+
+@pytest.mark.parametrize("tile", [1, 2], ids=["128", "256"])
+def test_linear_x6_lost_handover_is_loud(tile):
+    """VERDICT r3 item 2 / ADVICE r3: a stream-K hand-over that never arrives must not yield a plausible result.  The test
+    hook keeps every publisher's flag down: the waiting workgroup gives up after its bounded wait, ORs the sticky status
+    word (ops.x6_raise_if_failed raises), poisons what it computed from the missing accumulators (NaN in the outputs of
+    the C-pass and of the plain product) -- and every later wait gives up at once, so the call takes ~0.25 s, not one
+    timeout per workgroup.  Afterwards the same call without the hook is clean and correct."""
+    import time
+    from transformer_explainability_amd import _lib, ops
+    T, in_f, out_f = 1100, 768, 2304
+    Xd, Wd, bd, Rd, Y = _x6_operands(T, in_f, out_f, 310)
+    was = ops.USE_LINEAR_X6
+    ops.USE_LINEAR_X6 = True
+    try:
+        cache = {}
+        ops.x6_raise_if_failed()
+        ops.X6_TILE = tile
+        good = ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)
+        wp = ops.x6_matrix_planes(Wd, False, cache)
+        ggood = ops.gemm_x6(Xd, wp, bd, out_f)
+        torch.cuda.synchronize()
+        assert not ops.x6_failed()
+        ops.X6_FLAGS = ops.TE_X6_TEST_SMALL_GRID | ops.TE_X6_TEST_DROP_HANDOVER
+        t0 = time.perf_counter()
+        bad = ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert ops.x6_failed(), "the sticky status word must be set"
+        assert not torch.isfinite(bad).all(), "outputs computed from missing accumulators must be NaN"
+        assert dt < 5.0, f"later waits must give up at once (took {dt:.1f} s)"
+        with pytest.raises(_lib.TeError, match="waited in vain"):
+            ops.x6_raise_if_failed()
+        assert not ops.x6_failed()                 # raising resets the word
+        gbad = ops.gemm_x6(Xd, wp, bd, out_f)
+        torch.cuda.synchronize()
+        assert ops.x6_failed() and not torch.isfinite(gbad).all()
+        with pytest.raises(_lib.TeError):
+            ops.x6_raise_if_failed()
+        record(f"x6_lost_handover(tile={tile})", seconds_for_failing_rule=dt, nan_fraction=float(torch.isnan(bad).float().mean()))
+        # the per-call check of the C ABI sees it too
+        ops.X6_CHECK = True
+        with pytest.raises(_lib.TeError):
+            ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)
+        ops.X6_CHECK = False
+        for t in ops._x6_status.values():
+            t.zero_()
+        # the hook gone: clean and bit-identical again (on the small grid too)
+        ops.X6_FLAGS = ops.TE_X6_TEST_SMALL_GRID
+        assert torch.equal(ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache), good)
+        assert torch.equal(ops.gemm_x6(Xd, wp, bd, out_f), ggood)
+        ops.x6_raise_if_failed()
+    finally:
+        ops.USE_LINEAR_X6, ops.X6_CHECK, ops.X6_TILE, ops.X6_FLAGS = was, False, 0, 0
+        for t in ops._x6_status.values():
+            t.zero_()
+
+
+def test_linear_x6_two_launches_on_two_streams_vit_b16_b64():
+    """two persistent x6 rules side by side (two HIP streams) at the headline's own size -- T = 64 x 197
+    rows, the qkv and fc2 shapes, whose C- / Z-passes are stream-K launches that want every CU.  A workgroup only ever
+    waits for a lower-numbered workgroup of its OWN launch, whose publishing fragment is the first thing that one runs, so
+    two launches cannot deadlock each other; whatever the dispatcher does, the call must end (bounded waits) and either
+    give the serial bits or raise."""
+    from transformer_explainability_amd import _lib, ops
+    T = 64 * 197
+    a = _x6_operands(T, 768, 2304, 320)
+    b = _x6_operands(T, 3072, 768, 330)
+    was = ops.USE_LINEAR_X6
+    ops.USE_LINEAR_X6 = True
+    try:
+        ca, cb = {}, {}
+        ops.x6_raise_if_failed()
+        run = lambda o, c: ops.linear_relprop(o[3], o[0], o[1], Y=o[4], bias=o[2], cache=c)      # noqa: E731
+        ra, rb = run(a, ca), run(b, cb)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(4):
+            s1.wait_stream(torch.cuda.current_stream())
+            s2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s1):
+                xa = run(a, ca)
+            with torch.cuda.stream(s2):
+                xb = run(b, cb)
+            torch.cuda.current_stream().wait_stream(s1)
+            torch.cuda.current_stream().wait_stream(s2)
+            outs.append((xa, xb))
+        torch.cuda.synchronize()
+        try:
+            ops.x6_raise_if_failed()
+        except _lib.TeError:
+            record("x6_two_streams", outcome="raised")
+            assert any(not torch.isfinite(x).all() for pair in outs for x in pair)
+            return
+        record("x6_two_streams", outcome="bitwise equal to the serial results")
+        for xa, xb in outs:
+            assert torch.equal(xa, ra) and torch.equal(xb, rb)
+    finally:
+        ops.USE_LINEAR_X6 = was
+        for t in ops._x6_status.values():
+            t.zero_()
+
+
 @pytest.mark.parametrize("T,in_f,out_f", [(140, 256, 192), (140, 256, 256), (300, 768, 768)],
                          ids=["fp32-mfma", "x6-128", "x6-256"])
 def test_linear_from_forward_output_cancellation(T, in_f, out_f):

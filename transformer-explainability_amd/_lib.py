@@ -63,14 +63,14 @@ SIGNATURES = {
     "te_linear_x6_planes_bytes": (_SZ, [_I64, _I64]),
     "te_linear_x6_prepare_weights_f32": (_I, [_P, _I64, _I64, _P, _SZ, _P]),
     "te_linear_x6_split_abs_f32": (_I, [_P, _I64, _I64, _P, _SZ, _P]),
-    "te_linear_relprop_x6_f32": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _SZ,
+    "te_linear_relprop_x6_f32": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P, _SZ,
                                       _P]),
     "te_linear_relprop_x6_check": (_I, [_P, _I64, _I64, _I64, _P]),
     "te_gemm_x6_supported": (_I, [_I64, _I64, _I64]),
     "te_gemm_x6_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_linear_x6_split_matrix_f32": (_I, [_P, _I64, _I64, _I, _P, _SZ, _P]),
     "te_linear_x6_split_dual_f32": (_I, [_P, _I64, _I64, _P, _P, _SZ, _P]),
-    "te_gemm_x6_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P, _SZ, _P]),
+    "te_gemm_x6_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P, _SZ, _P]),
     "te_layernorm_supported": (_I, [_I64]),
     "te_layernorm_forward_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "te_layernorm_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),

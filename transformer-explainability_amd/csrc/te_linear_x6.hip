@@ -56,7 +56,8 @@ constexpr int kRB = 3 * kFrag;                // one 32-row block, one K16 step
 constexpr int kTileT = 256;                   // activation rows per tile (4 wave columns x 64)
 constexpr int kMinFrag = 4;                   // a cut closer than this many K-steps to a tile boundary snaps onto it
 constexpr float kCancelTol = 0.0078125f;      // as te_linear.hip
-constexpr unsigned kSpinLimit = 1u << 22;     // bounded wait for a predecessor's accumulators (~1 s): never hang the GPU
+constexpr int kSpinMillis = 250;               // bounded wait for a predecessor's accumulators: never hang the GPU
+constexpr int kErrWord = 512;                  // flags[0 .. 511] = hand-over flags of a pass, flags[kErrWord] = its error word
 
 enum { MODE_Z = 0, MODE_C = 1, MODE_G = 2 };      // Z-pass, C-pass, plain GEMM out = B A^T + bias
 
@@ -197,7 +198,11 @@ struct X6Params {
   int64_t T;
   int in_f, out_f;
   float* partial;              // [grid][threads][32] float4: accumulators of a cut tile
-  unsigned* flags;             // [grid], zero before the launch; [grid] = error word
+  unsigned* flags;             // [grid] hand-over flags, zero before the launch; [kErrWord] = error word of this pass
+  unsigned* status;            // sticky error word (the caller's, else = flags + kErrWord): OR-ed, never cleared here
+  long long spin_ticks;        // wall_clock64 ticks a workgroup waits for a predecessor before it gives up
+  int drop_handover;           // TE_X6_TEST_DROP_HANDOVER: publishers keep their flag down (tests: a wait must expire)
+  int small_grid;              // TE_X6_TEST_SMALL_GRID: 16 workgroups (tests: stream-K cuts on small shapes)
   // Z-pass epilogue
   const float* R;
   const float* Y;
@@ -229,14 +234,18 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_keep, unsigned& hi_keep
 // STUDY (only instantiated under -DTE_X6_STUDY, benchmarks/x6_bench.py --study): timing-only ablations of the main loop --
 // 1: no global loads after the first stage; 2: + no barrier; 3: + no LDS reads (MFMAs on resident fragments);
 // 4: the shipped loop without the epilogue.  Their results are garbage by construction.
-template <int WM, int MODE, int STUDY = 0>
+// NST = LDS stages: 2 (stage ks + 1 lands while ks is multiplied) or 3 (prefetch distance 2: a fill that misses the
+// XCD's L2 -- workgroups at different k offsets of shared panels, i.e. every stream-K launch -- has two steps to land).
+template <int WM, int MODE, int STUDY = 0, int NST = 2>
 __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
+  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
   constexpr int NW = 4 * WM;                         // waves
   constexpr int G = (MODE == MODE_C) ? 6 : 3;        // pieces of one A group (32 rows [x 2 signs]) per K16 step
   constexpr int NPA = 12 * WM, NPB = 24;             // 1-KiB pieces of one stage: weight side, activation side
   constexpr int NP = NPA + NPB;
   constexpr int PBW = NPB / 3 / NW;                  // activation-side 32-row blocks each wave stages (2 or 1)
   constexpr int STAGE = NP * kFrag;
+  constexpr int LPS = 3 + 3 * PBW;                   // direct-to-LDS loads one stage_in issues per lane
   constexpr int GROUPS = NPA / G;                    // A groups per tile: 4 WM (Z) or 2 WM (C)
   constexpr bool FULL = (STUDY == 0 || STUDY >= 4);  // study builds: 5 = shipped + time stamps, 6 = no epilogue + stamps
   constexpr bool EPI = (STUDY == 0 || STUDY == 5), PROF = (STUDY == 5 || STUDY == 6);
@@ -327,20 +336,34 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     }
     f32x16 acc[4][2];
     if (k0 > 0) {
-      // the head of this tile was computed by the workgroup 8 below: wait for its accumulators, continue its chain
+      // the head of this tile was computed by the workgroup 8 below: wait for its accumulators, continue its chain.
+      // The wait is bounded (a predecessor that never becomes resident must not hang the GPU) and LOUD: on expiry the
+      // workgroup ORs the caller's sticky status word and its pass's error word and continues from NaN accumulators, so
+      // the C-pass / plain-GEMM outputs of the tile are NaN (the Z-pass then takes its exact fallback for every element
+      // of the tile: correct values, slowly).  Once any workgroup of any launch has failed, later waits give up at once.
+      unsigned* const ok_word = reinterpret_cast<unsigned*>(smem + NST * STAGE + NW * 512);
       if (threadIdx.x == 0) {
-        unsigned spins = 0;
+        unsigned spins = 0, ok = 1u;
+        const long long t_begin = wall_clock64();
         while (__hip_atomic_load(p.flags + bid - 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           __builtin_amdgcn_s_sleep(8);
-          if (++spins > kSpinLimit) {
-            __hip_atomic_store(p.flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((++spins & 63u) == 0u &&
+              (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+               wall_clock64() - t_begin > p.spin_ticks)) {
+            ok = 0u;
             break;
           }
         }
+        if (!ok) {
+          __hip_atomic_fetch_or(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.flags + kErrWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(p.flags + bid - 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ok_word = ok;
       }
       __syncthreads();
+      const bool handed_over = __builtin_amdgcn_readfirstlane(*ok_word) != 0u;
       const f32x4* ip = reinterpret_cast<const f32x4*>(in_part) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -350,7 +373,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
           for (int c = 0; c < 4; ++c) {
             const f32x4 v = ip[c * 64];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[mi][ni][4 * c + e] = v[e];
+            for (int e = 0; e < 4; ++e) acc[mi][ni][4 * c + e] = handed_over ? v[e] : __builtin_nanf("");
           }
           ip += 4 * 64;
           asm volatile("" : "+v"(ip));      // one running pointer, not 32 precomputed ones
@@ -372,8 +395,9 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         prof_steps += k1 - k0;
       }
     }
-    // ---- main loop: stage ks + 1 lands while stage ks is multiplied ----
+    // ---- main loop: stage ks + 1 (and, NST = 3, ks + 2) lands while stage ks is multiplied ----
     stage_in(0, 0);
+    if constexpr (NST == 3) stage_in(1, (k0 + 1 < k1) ? 1 : 0);
     int st = 0;
     bf16x8 a[4][3], b[2][3];
     if constexpr (STUDY == 3) {
@@ -389,9 +413,16 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         for (int q = 0; q < 3; ++q) a[mi][q] = *reinterpret_cast<const bf16x8*>(smem + wm * (4 * kRB) + lane16 + mi * kRB + q * kFrag);
     }
     for (int ks = k0; ks < k1; ++ks) {
-      // hipcc does not wait for direct-to-LDS loads at a barrier: this step's stage has landed (all waves) after ...
-      if constexpr (FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if constexpr (FULL || STUDY == 1) __syncthreads();   // ... and the other stage is free again
+      // This step's stage has landed (own loads: counted vmcnt -- loads retire in issue order, so with three stages the
+      // LPS loads of the youngest fill stay in flight across the barrier; every wave's: the barrier), and the stage of
+      // step ks - 1 is free again (every wave finished its fragment reads before it arrived here: lgkmcnt(0) at the last
+      // MFMA round).  A RAW s_barrier: __syncthreads() carries a workgroup fence, for which hipcc drains vmcnt(0) -- a
+      // direct-to-LDS load is a pending LDS write -- i.e. it would cut the prefetch distance back to one step.
+      if constexpr (FULL) {
+        if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      if constexpr (FULL || STUDY == 1) __builtin_amdgcn_s_barrier();
       const unsigned char* sA = smem + st * STAGE + wm * (4 * kRB) + lane16;
       const unsigned char* sB = smem + st * STAGE + NPA * kFrag + wn * (2 * kRB) + lane16;
       // The order below is pinned with sched_barrier: left to itself hipcc's scheduler flips between an order that
@@ -425,7 +456,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       X6_RD_HEAD(0);
       X6_RD_TAIL(0);                                                 // 6 issued
       // the next step's stage is requested before the first MFMA (a direct-to-LDS load between MFMAs costs issue slots)
-      if constexpr (FULL) stage_in(st ^ 1, (ks + 1 < k1) ? 1 : 0);
+      if constexpr (FULL) stage_in((st + NST - 1) % NST, (ks + NST - 1 < k1) ? 1 : 0);
       X6_WAIT(4); X6_MM(0, 0, 0);
       X6_WAIT(3); X6_MM(1, 0, 0);
       X6_WAIT(2); X6_MM(1, 1, 0); X6_MM(0, 1, 0);
@@ -459,7 +490,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
 #undef X6_MM
 #undef X6_RD_HEAD
 #undef X6_RD_TAIL
-      st ^= 1;
+      st = (st + 1 == NST) ? 0 : st + 1;
     }
 
     if constexpr (PROF) {
@@ -490,7 +521,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(p.flags + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!p.drop_handover) __hip_atomic_store(p.flags + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (PROF) prof_pub += wall_clock64() - prof_t1;
       }
       continue;
@@ -532,7 +563,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       }
       // the wave's 128 bias values go through a private 512-B LDS slot: reading them back counts on lgkmcnt, so no wait
       // for a bias value drains the prefetched R / Y loads of the next block
-      float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * 128;
+      float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 128;
       if (lane < 32) {
         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
         if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (4 * WM) + wm * 4) * 32 + lane * 4);
@@ -629,7 +660,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       }
     } else if constexpr (MODE == MODE_G) {
       // plain product: out[t][m] = acc + bias[m] (fp32 row-major [T, M]); the wave's 128 bias values through its LDS slot
-      float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE) + wave * 128;
+      float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 128;
       if (lane < 32) {
         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
         if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (4 * WM) + wm * 4) * 32 + lane * 4);
@@ -715,19 +746,30 @@ inline int pick_wm(int64_t in_f, int64_t out_f) {
   return 0;
 }
 
-template <int WM, int MODE, int STUDY = 0>
+// wall_clock64 rate of the current device (constant-frequency counter), per device, cached
+inline long long spin_ticks_for_current_device() {
+  static long long cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cached[dev] == 0) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    cached[dev] = (long long)khz * kSpinMillis;
+  }
+  return cached[dev];
+}
+
+template <int WM, int MODE, int STUDY = 0, int NST = 2>
 int launch_x6(const X6Params& p, hipStream_t stream) {
   constexpr int NP = 12 * WM + 24;
-  constexpr int lds = 2 * NP * kFrag + 4 * WM * 512;      // two stages + one 512-B bias slot per wave
-  static bool configured = false;      // idempotent attribute of the code object (not data-path state)
-  auto kern = x6_kernel<WM, MODE, STUDY>;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  constexpr int lds = NST * NP * kFrag + 4 * WM * 512 + 16;      // stages + one 512-B bias slot per wave + the hand-over word
+  static_assert(lds <= 160 * 1024, "LDS of one workgroup");
+  auto kern = x6_kernel<WM, MODE, STUDY, NST>;
+  // an attribute of the code object ON THE CURRENT DEVICE: set per launch (idempotent, no data-path state)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return (int)e;
   const int64_t tiles = (int64_t)p.ntm * p.ntn;
-  const int max_spx = (WM == 2) ? 32 : 64;
+  const int max_spx = p.small_grid ? 2 : (WM == 2) ? 32 : 64;
   const int spx = (int)std::min<int64_t>(max_spx, std::max<int64_t>(1, te_ceil_div(tiles, 8)));
   // Stream-K or whole tiles?  With equal (tile, k) ranges the workgroups of an XCD sit at different k offsets of their
   // tiles and nothing one of them fetches is still in the 4 MB L2 when its neighbour needs it; cut at tile boundaries
@@ -737,8 +779,18 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
   X6Params q = p;
   const double r = (double)tiles / (8.0 * spx);
   if (!q.whole_tiles_forced) q.whole_tiles = (std::ceil(r) <= kWholeTileSlack * r) ? 1 : 0;
+  if (!q.status) q.status = q.flags + kErrWord;
+  q.spin_ticks = spin_ticks_for_current_device();
   kern<<<dim3(8 * spx), dim3(256 * WM), lds, stream>>>(q);
   return TE_OK;
+}
+
+// WM = 2 runs three LDS stages (148 KiB, one workgroup per CU either way) unless the caller pins two; WM = 1 keeps two
+// (74 KiB: two workgroups per CU)
+template <int MODE>
+int launch_x6_mode(int wm, bool two_stages, const X6Params& p, hipStream_t stream) {
+  if (wm == 2) return two_stages ? launch_x6<2, MODE, 0, 2>(p, stream) : launch_x6<2, MODE, 0, 3>(p, stream);
+  return launch_x6<1, MODE, 0, 2>(p, stream);
 }
 
 }  // namespace
@@ -829,8 +881,11 @@ extern "C" size_t te_gemm_x6_workspace_bytes(int64_t T, int64_t K, int64_t M) {
 }
 
 extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* w_planes, const float* bias, float* out,
-                              int64_t T, int64_t K, int64_t M, void* ws, size_t ws_bytes, te_stream_t stream_) {
+                              int64_t T, int64_t K, int64_t M, int flags, unsigned* status, void* ws, size_t ws_bytes,
+                              te_stream_t stream_) {
   if ((!X && !x_planes) || !w_planes || !out) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(3 | TE_X6_STAGES_2 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0 || (flags & 3) == 3)
+    return TE_ERR_INVALID_ARG;
   if (!te_gemm_x6_supported(T, K, M)) return TE_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < te_gemm_x6_workspace_bytes(T, K, M) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
   if ((X && !te_aligned16(X)) || !te_aligned16(out) || !te_aligned16(w_planes) || (bias && !te_aligned16(bias)) ||
@@ -851,7 +906,12 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   }
   int wm = (M % 256 == 0) ? 2 : 1;
   if (wm == 2 && te_ceil_div(T, kTileT) * (M / 256) < 192) wm = 1;
+  if ((flags & 3) == TE_X6_TILE_128) wm = 1;
+  if ((flags & 3) == TE_X6_TILE_256 && M % 256 == 0) wm = 2;
   X6Params p{};
+  p.status = status;
+  p.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
+  p.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
 #ifdef TE_X6_STUDY
   if (const char* e = getenv("TE_X6_ORDER")) p.t_fast = atoi(e);
   if (const char* e = getenv("TE_X6_SNAP")) p.whole_tiles = atoi(e), p.whole_tiles_forced = 1;
@@ -882,7 +942,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   if (pe && atoi(pe) == 1) rc = (wm == 2) ? launch_x6<2, MODE_G, 5>(p, stream) : launch_x6<1, MODE_G, 5>(p, stream);
   else
 #endif
-  rc = (wm == 2) ? launch_x6<2, MODE_G>(p, stream) : launch_x6<1, MODE_G>(p, stream);
+  rc = launch_x6_mode<MODE_G>(wm, (flags & TE_X6_STAGES_2) != 0, p, stream);
   if (rc != TE_OK) return rc;
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
@@ -897,8 +957,8 @@ extern "C" size_t te_linear_relprop_x6_workspace_bytes(int64_t T, int64_t in_f, 
 extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
                                         int64_t rows_per_sample, const float* X, const float* W, const void* w_planes,
                                         const void* x_planes, const float* Y, const float* bias, float* out, int64_t T,
-                                        int64_t in_f, int64_t out_f, int flags, void* ws, size_t ws_bytes,
-                                        te_stream_t stream_) {
+                                        int64_t in_f, int64_t out_f, int flags, unsigned* status, void* ws,
+                                        size_t ws_bytes, te_stream_t stream_) {
   if (!R || !X || !W || !w_planes || !Y || !out || T <= 0) return TE_ERR_INVALID_ARG;
   if (!te_linear_relprop_x6_supported(T, in_f, out_f)) return TE_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < te_linear_relprop_x6_workspace_bytes(T, in_f, out_f) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
@@ -939,11 +999,18 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   int wm_c = (wm_max == 2 && ntn_ * (in_f / 128) >= 256) ? 2 : 1;
   if ((flags & 3) == TE_X6_TILE_128) wm_z = wm_c = 1;
   if ((flags & 3) == TE_X6_TILE_256) wm_z = wm_c = wm_max;
+  if (((flags >> 10) & 3) == TE_X6_TILE_128) wm_z = 1;              // per-pass pins (measurement)
+  if (((flags >> 10) & 3) == TE_X6_TILE_256) wm_z = wm_max;
+  if (((flags >> 12) & 3) == TE_X6_TILE_128) wm_c = 1;
+  if (((flags >> 12) & 3) == TE_X6_TILE_256) wm_c = wm_max;
 #ifdef TE_X6_STUDY
   const int study = (flags >> 5) & 7;      // study builds: run ablation `study` of the main loop instead
-  flags &= 0x1f;
+  flags &= ~0xe0;
 #endif
-  if ((flags & ~0x1f) != 0 || (flags & 3) == 3) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(0x1f | TE_X6_STAGES_2 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0 || (flags & 3) == 3 ||
+      ((flags >> 10) & 3) == 3 || ((flags >> 12) & 3) == 3)
+    return TE_ERR_INVALID_ARG;
+  const bool two_stages = (flags & TE_X6_STAGES_2) != 0;
   int wm = 0;
   X6Params p{};
 #ifdef TE_X6_STUDY
@@ -966,6 +1033,9 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   p.rs_stride = r_scale_stride;
   p.rps = (int)(r_scale ? rows_per_sample : 1);
   p.out = out;
+  p.status = status;
+  p.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
+  p.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
   int rc;
   if (phases & TE_X6_PHASE_Z) {   // Z-pass: D[j][t] = sum_k |W|[j][k] |X|[t][k]
     p.A = wz;
@@ -986,7 +1056,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     else if (wm == 1 && study == 5) rc = launch_x6<1, MODE_Z, 5>(p, stream);
     else
 #endif
-    rc = (wm == 2) ? launch_x6<2, MODE_Z>(p, stream) : launch_x6<1, MODE_Z>(p, stream);
+    rc = launch_x6_mode<MODE_Z>(wm, two_stages, p, stream);
     if (rc != TE_OK) return rc;
   }
   if (phases & TE_X6_PHASE_C) {   // C-pass: D[(i, +-)][t] = sum_j W+-[j][i] S[t][j]
@@ -1008,7 +1078,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     else if (wm == 1 && study == 5) rc = launch_x6<1, MODE_C, 5>(p, stream);
     else
 #endif
-    rc = (wm == 2) ? launch_x6<2, MODE_C>(p, stream) : launch_x6<1, MODE_C>(p, stream);
+    rc = launch_x6_mode<MODE_C>(wm, two_stages, p, stream);
     if (rc != TE_OK) return rc;
   }
   TE_RETURN_IF_LAUNCH_FAILED();

@@ -77,6 +77,11 @@ class LRP:
     def generate_LRP(self, input, index=None, method="transformer_attribution", is_ablation=False, start_layer=0):
         return self._generate(input, index, method, is_ablation, start_layer)
 
+    def check(self):
+        """Raise TeError if any x6 Linear kernel since the last check lost a stream-K hand-over (the affected maps carry
+        NaN).  Synchronises the device: call it where the maps are read back anyway, never inside a step."""
+        ops.x6_raise_if_failed(next(self.model.parameters()).device)
+
     def _generate(self, input, index, method, is_ablation, start_layer):
         output = self.model(input)
         kwargs = {"alpha": 1}
@@ -282,6 +287,10 @@ class Generator:
 
     def forward(self, input_ids, attention_mask):
         return self.model(input_ids, attention_mask)
+
+    def check(self):
+        """As LRP.check(): raise if an x6 Linear kernel lost a hand-over since the last check (synchronises)."""
+        ops.x6_raise_if_failed(next(self.model.parameters()).device)
 
     def _explain(self, input_ids, attention_mask, index, lowest_layer=0):
         """forward, attention-gradient backward, relprop.  With prune=True only the layers >= lowest_layer are served."""

@@ -119,7 +119,57 @@ USE_FORWARD_PRODUCTS = True
 USE_LINEAR_X6 = os.environ.get("TE_LINEAR_X6", "1") not in ("", "0")
 X6_CHECK = False     # tests: synchronise after every x6 rule and raise if a bounded hand-over wait expired
 X6_TILE = 0          # te_relprop.h TE_X6_TILE_*: 0 auto, 1 = 128-row weight tiles (measurement knob; results are identical)
+X6_FLAGS = 0         # extra te_relprop.h flag bits for every x6 launch (TE_X6_STAGES_2, per-pass tile pins, the test hook)
 TE_X6_PHASE_SPLIT, TE_X6_PHASE_Z, TE_X6_PHASE_C = 4, 8, 16
+TE_X6_STAGES_2, TE_X6_TEST_DROP_HANDOVER, TE_X6_TILE_Z_SHIFT, TE_X6_TILE_C_SHIFT, TE_X6_TEST_SMALL_GRID = 0x100, 0x200, 10, 12, 0x4000
+
+# A workgroup of an x6 kernel that continues a tile another workgroup started waits for that one's accumulators; the wait
+# is bounded, and a wait that expires must never yield a plausible-looking map (VERDICT r3 / ADVICE r3).  Every x6 launch
+# of this process ORs into ONE sticky device word per GPU; the kernels also poison what they computed from the missing
+# accumulators with NaN.  Nothing on the hot path reads the word (no synchronisation is added to a step): the generators
+# expose ``check()`` and ``x6_raise_if_failed`` is called where a caller synchronises anyway (bench.py after its final
+# synchronise, the sweep after its gather, tests after every rule).
+_x6_status = {}
+
+
+def x6_status(device) -> Tensor:
+    """The sticky hand-over status word of `device` (int32 [4], word 0 is the one the kernels OR into)."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = _x6_status.get(dev.index)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.TeError("the x6 status word must exist before a HIP graph is captured: run the step once eagerly "
+                               "(GraphedLRP / GraphedCall warm up before they capture)")
+        t = _x6_status[dev.index] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return t
+
+
+def x6_failed(device=None) -> bool:
+    """Synchronises `device` (default: every GPU an x6 kernel ran on) and reports whether a hand-over wait ever expired."""
+    keys = list(_x6_status) if device is None else [torch.device(device).index or 0]
+    bad = False
+    for k in keys:
+        t = _x6_status.get(k)
+        if t is not None:
+            torch.cuda.synchronize(t.device)
+            bad = bad or bool(int(t[0].item()) != 0)
+    return bad
+
+
+def x6_raise_if_failed(device=None, reset: bool = True):
+    """Raise TeError if any x6 launch since the last reset lost a hand-over (its outputs are NaN-poisoned and invalid).
+    Synchronises; call it where the caller synchronises anyway."""
+    if x6_failed(device):
+        if reset:
+            for t in _x6_status.values():
+                t.zero_()
+        raise _lib.TeError("an x6 Linear kernel waited in vain for the accumulators of a tile it shares with another "
+                           "workgroup (bounded stream-K hand-over expired): the affected outputs were poisoned with NaN and "
+                           "every map computed since the last check is invalid.  Typical causes: several persistent x6 "
+                           "launches competing for the CUs (more than one step in flight), a profiler or another process "
+                           "holding CUs.  Re-run the step; set TE_LINEAR_X6=0 to use the fp32-MFMA kernels instead")
 
 
 def x6_weight_planes(W: Tensor, cache: Optional[dict] = None) -> Tensor:
@@ -216,7 +266,8 @@ def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_n
                 _lib.check(lib.te_linear_x6_split_dual_f32(_ptr(Xc), T, K, _ptr(xs), _ptr(xa), nb, _stream(Xc)),
                            "te_linear_x6_split_dual_f32")
                 keep_abs["x_abs_planes"] = (_x_abs_key(X, T, K), xa)
-            _lib.check(lib.te_gemm_x6_f32(_ptr(Xc), _ptr(xs), _ptr(w_planes), _ptr(bc), _ptr(out), T, K, M, _ptr(ws),
+            _lib.check(lib.te_gemm_x6_f32(_ptr(Xc), _ptr(xs), _ptr(w_planes), _ptr(bc), _ptr(out), T, K, M,
+                                          (X6_TILE | X6_FLAGS) & ~0x3c00, _ptr(x6_status(Xc.device)), _ptr(ws),
                                           ws.numel(), _stream(Xc)), "te_gemm_x6_f32")
     return out.reshape(*lead, M)
 
@@ -260,11 +311,13 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
                 xa = hit[1]
         with _on_device(Xc) as lib:
             ws = _ws(lib.te_linear_relprop_x6_workspace_bytes(T, in_f, out_f), Xc)
+            status = x6_status(Xc.device)
 
             def call(flags):
                 _lib.check(lib.te_linear_relprop_x6_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc), _ptr(planes),
                                                         _ptr(xa), _ptr(Yc), _ptr(bc), _ptr(out), T, in_f, out_f,
-                                                        X6_TILE | flags, _ptr(ws), ws.numel(), _stream(Xc)),
+                                                        X6_TILE | X6_FLAGS | flags, _ptr(status), _ptr(ws), ws.numel(),
+                                                        _stream(Xc)),
                            "te_linear_relprop_x6_f32")
             if KERNEL_TIMER is None:
                 call(0)
@@ -284,8 +337,10 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
             if X6_CHECK:
                 rc = lib.te_linear_relprop_x6_check(_ptr(ws), T, in_f, out_f, _stream(Xc))
                 if rc != 0:
+                    status.zero_()
                     raise _lib.TeError(f"te_linear_relprop_x6_f32({T},{in_f},{out_f}): a workgroup waited in vain for the "
                                        f"accumulators of a shared tile (status {rc}); the result is invalid")
+                x6_raise_if_failed(Xc.device)
         return out.reshape(*lead, in_f)
     if KERNEL_TIMER is not None and fast_ok:
         # bench.py roofline probe: same two kernels, launched one by one so that each launch can be
