@@ -583,6 +583,14 @@ def main():
         maps = step()
         torch.cuda.synchronize()
         log(f"warmup step {w_} done")
+    if graphed is not None and not args.no_roofline and args.warmup > 0:
+        # The probe step of the timed region runs EAGERLY; capture emptied the caching allocator (GraphedCall), so its ~1000
+        # allocations would each be a fresh hipMalloc inside the timed region (measured: 100-350 ms of host time for one
+        # step, launches stalled for up to 17 ms between their two events).  One untimed eager step leaves the blocks in
+        # the allocator's cache, exactly as the graph's own warm-up does for the capture.
+        step(eager=True)
+        torch.cuda.synchronize()
+        log("warmup of the eager probe path done")
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -649,6 +657,14 @@ def main():
             ops.USE_LINEAR_X6 = True
             ops.X6_GEMM = args.x6_gemm
 
+    if rank == 0 and os.environ.get("TE_BENCH_DUMP"):      # per-launch probe times by (group, algorithmic work) -> stderr
+        import collections
+        by = collections.defaultdict(list)
+        for n_, f_, b_, s_, e_ in timer.records:
+            by[(n_, round(f_ / 1e9, 1), round(b_ / 1e6, 1))].append(round(s_.elapsed_time(e_) * 1e3, 1))
+        for k_, v_ in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+            if sum(v_) > 300:
+                log(f"probe {k_[0]} gflop {k_[1]} mb {k_[2]}: n {len(v_)} us {sorted(v_)[len(v_) // 2]} (min {min(v_)}, max {max(v_)})")
     if rank == 0:
         value = world * B * args.steps / elapsed
         idx = CONFIGS[args.config][0]

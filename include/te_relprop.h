@@ -275,7 +275,8 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
  * flags: TE_X6_TILE_AUTO (per pass: 256 weight rows per tile / one 512-thread workgroup per CU where that gives every CU
  * a tile, else 128 rows / two 256-thread workgroups per CU; the result does not depend on the tile geometry, bit for
  * bit), TE_X6_TILE_128 / TE_X6_TILE_256 pin it; shifted left by TE_X6_TILE_Z_SHIFT / TE_X6_TILE_C_SHIFT they pin one pass.
- * TE_X6_STAGES_2: two LDS stages instead of three in the 256-row geometry (measurement; same results).
+ * TE_X6_TILE_128x128: 128 x 128 tiles, three 256-thread workgroups per CU (launches with few weight rows).
+ * TE_X6_STAGES_3: three LDS stages instead of two in the 256-row geometry (measurement; same results).
  *
  * Failure is loud.  A workgroup that continues a tile another workgroup started waits for that one's accumulators for at
  * most 250 ms.  If the wait expires it ORs 1 into *status -- a caller-owned, caller-zeroed device word that is NEVER
@@ -288,7 +289,8 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
 #define TE_X6_TILE_AUTO 0
 #define TE_X6_TILE_128 1
 #define TE_X6_TILE_256 2
-#define TE_X6_STAGES_2 0x100
+#define TE_X6_TILE_128x128 3
+#define TE_X6_STAGES_3 0x100
 #define TE_X6_TEST_DROP_HANDOVER 0x200
 #define TE_X6_TEST_SMALL_GRID 0x4000   /* tests: a persistent grid of 16 workgroups, so that small shapes get stream-K cuts */
 #define TE_X6_TILE_Z_SHIFT 10
@@ -317,7 +319,7 @@ int te_linear_relprop_x6_check(const void* ws, int64_t T, int64_t in_f, int64_t 
  * modules/layers_ours.py:207 = nn.Linear): out [T, M] = X [T, K] . W^T + bias [M] with W given as signed P3 planes of an
  * [M, K] matrix.  te_linear_x6_split_matrix_f32 builds such planes from a row-major [rows, K] matrix (transposed = 0) or
  * from its transpose stored as [K, rows] (transposed = 1: the planes of W^T for d_x = d_y W).  M % 128 == 0, K % 16 == 0.
- * x_planes = NULL: X is split into the workspace first.  flags: TE_X6_TILE_* | TE_X6_STAGES_2 | TE_X6_TEST_DROP_HANDOVER;
+ * x_planes = NULL: X is split into the workspace first.  flags: TE_X6_TILE_* | TE_X6_STAGES_3 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID;
  * status: as te_linear_relprop_x6_f32. */
 int te_gemm_x6_supported(int64_t T, int64_t K, int64_t M);
 size_t te_gemm_x6_workspace_bytes(int64_t T, int64_t K, int64_t M);
@@ -352,8 +354,9 @@ int te_attention_backward_f32(const float* d_out, const float* qkv, const float*
  * N <= 640 (ViT-L/16 at 384^2: 577, baselines/ViT/ViT_LRP.py:419-425; BERT: 512), q / k / v / out / gradients as
  * [B,H,N,64] views with element strides (sb, sh, sn) -- the fused 'b n (qkv h d)' activation of ViT or the three separate
  * 'b n (h d)' activations of BERT (BERT_explainability/modules/BERT/BERT.py:307-365).
- *   forward : z_qk (optional) = q k^T unscaled ; x = z_qk * scale + mask[b, key] (mask [B,N] additive, NULL = none;
- *             x_scaled optional: the Add module's first operand, BERT.py:341-342) ; attn = softmax(x) ; out = attn v
+ *   forward : z_qk (optional) = q k^T unscaled ; x_scaled (optional) = z_qk * scale, WITHOUT the mask: the first operand of
+ *             the Add module, BERT.py:339-342 (Add.relprop divides by x_scaled + mask: the mask must not be in it twice) ;
+ *             x = x_scaled + mask[b, key] (mask [B,N] additive, NULL = none) ; attn = softmax(x) ; out = attn v
  *   backward: d_attn = d_out v^T ; d_v = attn^T d_out ; need_qk: d_q = d_s k, d_k = d_s^T q with
  *             d_s = ((d_attn - rowsum(d_attn . attn)) . attn) * scale.  Workspace: B*H*N floats. */
 int te_attention_strided_supported(int64_t N, int64_t D);

@@ -115,11 +115,8 @@ def test_attention_producer_bert_layout(B, H, N, masked):
     tag = f"({B},{H},{N},{masked})"
     check("producer.bert.zqk" + tag, zqk, z, 2e-6)
     if masked:
-        live = (mask.expand_as(x) == 0)
-        check("producer.bert.x_live" + tag, torch.where(live, xsc, torch.zeros_like(xsc)),
-              torch.where(live, x.detach(), torch.zeros_like(x)), 2e-6)
-        # masked keys: -10000 + score, one fp32 ulp there is 1e-3: the two pipelines' scores differ by rounding
-        assert float((xsc - x.detach()).abs().max()) <= 2e-3
+        # the kernel's x_scaled = the scaled scores BEFORE the mask (the Add module's first operand, BERT.py:339-342)
+        check("producer.bert.x_scaled" + tag, xsc, (z / math.sqrt(D)).detach(), 2e-6)
     check("producer.bert.attn" + tag, attn, probs, 3e-6)
     check("producer.bert.out" + tag, out, ctx, 3e-6)
     for need_qk in (True, False):

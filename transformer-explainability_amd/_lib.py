@@ -13,7 +13,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 import torch  # noqa: F401  (must precede dlopen of libte_relprop: loads torch's libamdhip64 first)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libte_relprop.so")
+# (TE_RELPROP_LIB: measurement builds of the same sources under another name, e.g. an A/B of two -D variants in one process tree)
+LIB_PATH = os.environ.get("TE_RELPROP_LIB") or os.path.join(_PKG, "lib", "libte_relprop.so")
 
 TE_OK = 0
 TE_ERR_UNSUPPORTED = -3

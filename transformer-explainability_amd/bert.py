@@ -166,7 +166,7 @@ def make_bert_module(L):
         def _forward_fused(self, h1, h2, h3, attention_mask):
             """BERT.py:336-352 on the producer kernels.  The rule modules' caches (matmul1.X / .Y, add.X, matmul2.X / .Y)
             are views of the three Linear outputs and of the kernels' by-products, exactly the tensors the stock
-            forward would have cached there."""
+            forward would have cached there (add.X[0] = the scaled scores WITHOUT the mask, BERT.py:339-342)."""
             B, N, C = h1.shape
             H, D = self.num_attention_heads, self.attention_head_size
             ql, kl, vl = self.query(h1), self.key(h2), self.value(h3)

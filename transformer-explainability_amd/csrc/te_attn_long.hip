@@ -164,23 +164,24 @@ __global__ __launch_bounds__(kT) void attn_fwd_rows_kernel(const float* __restri
       if (c < nch) {
         const f32x4 z = *reinterpret_cast<const f32x4*>(rb + (c << 2));
         const int j = c << 2;
-        f32x4 xs;
+        f32x4 xs, xu;         // softmax input (scaled + mask); the scaled scores alone = Add.X[0] (BERT.py:339-342)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = z[e] * scale;                                          // 'dots * self.scale' / 'scores / sqrt(D)'
+          xu[e] = t;
           if (mrow && j + e < N) t = t + mrow[j + e];                      // BERT.py:341-342
           xs[e] = t;
         }
         if (row_ok) {
           if (j + 3 < N) {
             if (zqk) *reinterpret_cast<f32x4_u*>(zqk + rowoff + j) = z;
-            if (xsc) *reinterpret_cast<f32x4_u*>(xsc + rowoff + j) = xs;
+            if (xsc) *reinterpret_cast<f32x4_u*>(xsc + rowoff + j) = xu;
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (j + e < N) {
                 if (zqk) zqk[rowoff + j + e] = z[e];
-                if (xsc) xsc[rowoff + j + e] = xs[e];
+                if (xsc) xsc[rowoff + j + e] = xu[e];
               }
           }
         }

@@ -53,11 +53,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kFrag = 1024;                   // one plane fragment: 32 rows x 16 k bf16 as [kh][r][8]
 constexpr int kRB = 3 * kFrag;                // one 32-row block, one K16 step
-constexpr int kTileT = 256;                   // activation rows per tile (4 wave columns x 64)
 constexpr int kMinFrag = 4;                   // a cut closer than this many K-steps to a tile boundary snaps onto it
 constexpr float kCancelTol = 0.0078125f;      // as te_linear.hip
 constexpr int kSpinMillis = 250;               // bounded wait for a predecessor's accumulators: never hang the GPU
-constexpr int kErrWord = 512;                  // flags[0 .. 511] = hand-over flags of a pass, flags[kErrWord] = its error word
+constexpr int kErrWord = 1023;                 // flags[0 .. 767] = hand-over flags of a pass, flags[kErrWord] = its error word
+
 
 enum { MODE_Z = 0, MODE_C = 1, MODE_G = 2 };      // Z-pass, C-pass, plain GEMM out = B A^T + bias
 
@@ -190,7 +190,12 @@ struct X6Params {
   int64_t a_group_stride;      // bytes between consecutive 32-row groups of A  = nks * (3 or 6) KiB
   int64_t b_rb_stride;         // bytes between consecutive 32-row blocks of B  = nks * 3 KiB
   int nks;                     // K / 16
-  int ntm, ntn;                // tiles along the weight side / the activation side
+  int ksplit;                  // 1, or 2: every output = chain(k < K/2) + chain(k >= K/2), two work items per tile (kseg_rule)
+  float* seg_part;             // ksplit == 2: [tile][threads][accumulators] of the first segment ...
+  unsigned* seg_flags;         // ... and [tile] "it is there" flags, zero before the launch
+
+  int ntm, ntn;                // tiles along the weight side / the activation side (set by launch_x6 from rows_w, T)
+  int rows_w;                  // weight-side rows of the product: out_f (Z-pass, plain product), 2 in_f (C-pass: +/- pairs)
   int t_fast;                  // tile order inside the launch: 0 = weight side fastest, 1 = activation side fastest
   int whole_tiles;             // 1: ranges are cut at tile boundaries only (all workgroups of a round in k lock-step)
   int whole_tiles_forced;      // study builds: whole_tiles was set by the caller (TE_X6_SNAP)
@@ -236,13 +241,35 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_keep, unsigned& hi_keep
 // 4: the shipped loop without the epilogue.  Their results are garbage by construction.
 // NST = LDS stages: 2 (stage ks + 1 lands while ks is multiplied) or 3 (prefetch distance 2: a fill that misses the
 // XCD's L2 -- workgroups at different k offsets of shared panels, i.e. every stream-K launch -- has two steps to land).
-template <int WM, int MODE, int STUDY = 0, int NST = 2>
-__global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
+// Tile geometry WM (weight rows x activation rows of a workgroup tile; waves as NWM x NWN, each MI x 2 blocks of 32 x 32):
+//   2: 256 x 256, 2 x 4 waves of 128 x 64 (one 512-thread workgroup per CU)
+//   1: 128 x 256, 1 x 4 waves of 128 x 64 (two 256-thread workgroups per CU)
+//   0: 128 x 128, 2 x 2 waves of  64 x 64 (three 256-thread workgroups per CU, 168 VGPRs) -- round 4, for launches with
+//      few weight rows (out_f = 768: 150 / 300 tiles of the larger geometries for 256 CUs): every output is ONE k-ordered
+//      chain, so a tile takes K / 16 sequential steps whatever the schedule, and with one 4-wave workgroup on most CUs a
+//      SIMD held a single wave (1.38 us per step of 48 MFMAs: half the pipe idle).  Smaller tiles = shorter steps, 594
+//      tiles, three waves per SIMD to cover each other's LDS / barrier / fill latency.
+template <int WM>
+struct X6Geo {
+  static constexpr int NWM = (WM == 1) ? 1 : 2, NWN = (WM == 0) ? 2 : 4, MI = (WM == 0) ? 2 : 4;
+  static constexpr int NW = NWM * NWN, THREADS = 64 * NW, WPS = (WM == 0) ? 3 : 2;       // waves, waves per SIMD aimed at
+  static constexpr int TM = NWM * MI * 32, TT = NWN * 64;                                // tile: weight rows, activation rows
+  static constexpr int NPA = 3 * NWM * MI, NPB = 3 * NWN * 2;                            // 1-KiB pieces of one stage
+  static constexpr int ACC = MI * 2 * 16;                                                // accumulator floats per lane
+  static constexpr int MAX_SPX = (WM == 2) ? 32 : (WM == 1) ? 64 : 96;                   // workgroups per XCD
+};
+
+// KSPLIT = 2: a separate instantiation, so that launches without the K split carry none of its code or registers (with the
+// split as a run-time branch the Z-pass epilogue spilled 277 VGPRs and every un-split launch ran 6-16 % slower, measured).
+template <int WM, int MODE, int STUDY = 0, int NST = 2, int KSPLIT = 1>
+__global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(const X6Params p) {
   static_assert(NST == 2 || NST == 3, "two or three LDS stages");
-  constexpr int NW = 4 * WM;                         // waves
+  using GEO = X6Geo<WM>;
+  constexpr int NW = GEO::NW, NWM = GEO::NWM, NWN = GEO::NWN, MI = GEO::MI;
   constexpr int G = (MODE == MODE_C) ? 6 : 3;        // pieces of one A group (32 rows [x 2 signs]) per K16 step
-  constexpr int NPA = 12 * WM, NPB = 24;             // 1-KiB pieces of one stage: weight side, activation side
+  constexpr int NPA = GEO::NPA, NPB = GEO::NPB;      // 1-KiB pieces of one stage: weight side, activation side
   constexpr int NP = NPA + NPB;
+  static_assert(NPA / 3 == NW, "each wave stages one weight-side block");
   constexpr int PBW = NPB / 3 / NW;                  // activation-side 32-row blocks each wave stages (2 or 1)
   constexpr int STAGE = NP * kFrag;
   constexpr int LPS = 3 + 3 * PBW;                   // direct-to-LDS loads one stage_in issues per lane
@@ -255,16 +282,19 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int lane16 = lane * 16;
 
   // ---- this workgroup's range of the (tile, K-step) space: whole tiles per XCD, equal ranges inside one ----
   const int bid = blockIdx.x, spx = gridDim.x >> 3;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int nks = p.nks;
+  // A launch with ksplit = 2 runs two work items ("virtual tiles") per tile, K segment 0 and K segment 1, each a k-ordered
+  // chain of nks steps; an XCD walks all its segment-0 items, then its segment-1 items.
+  const int nks = p.nks / KSPLIT;                    // steps of one work item
   const int tiles = p.ntm * p.ntn;
   const int tx0 = (int)((int64_t)tiles * xcd / 8), tx1 = (int)((int64_t)tiles * (xcd + 1) / 8);
-  const int64_t iters = (int64_t)(tx1 - tx0) * nks;
+  const int ntx = tx1 - tx0;
+  const int64_t iters = (int64_t)ntx * KSPLIT * nks;
   auto cut = [&](int s) -> int64_t {
     int64_t b = iters * s / spx;
     const int r = (int)(b % nks);
@@ -282,8 +312,8 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
   const int full0 = tail ? f_tile + 1 : f_tile, full1 = (ke < nks) ? l_tile - 1 : l_tile;
   const int nseq = (head ? 1 : 0) + (full1 >= full0 ? full1 - full0 + 1 : 0) + (tail ? 1 : 0);
 
-  float* my_part = p.partial + (size_t)bid * (256 * WM) * 128;
-  const float* in_part = p.partial + (size_t)(bid - 8) * (256 * WM) * 128;
+  float* my_part = p.partial + (size_t)bid * GEO::THREADS * GEO::ACC;
+  const float* in_part = p.partial + (size_t)(bid - 8) * GEO::THREADS * GEO::ACC;
 
   for (int seq = 0; seq < nseq; ++seq) {
     int tile, k0, k1;
@@ -294,7 +324,9 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     } else {
       tile = full0 + seq - (head ? 1 : 0), k0 = 0, k1 = nks;
     }
-    tile += tx0;
+    const int seg = (KSPLIT == 2 && tile >= ntx) ? 1 : 0;      // K segment of this work item
+    tile = tile - seg * ntx + tx0;
+    const int kseg0 = seg * nks;                       // its first K16 step
     int tn, tm;
     if (p.t_fast) {
       tm = tile / p.ntn, tn = tile - tm * p.ntn;
@@ -306,14 +338,14 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     //      activation-side blocks -- each 3 KiB contiguous in memory and in the stage; wave-uniform pointers ----
     const unsigned char* srcA;
     if constexpr (MODE != MODE_C)
-      srcA = p.A + (int64_t)(tm * GROUPS + wave) * p.a_group_stride + (int64_t)k0 * kRB;
+      srcA = p.A + (int64_t)(tm * GROUPS + wave) * p.a_group_stride + (int64_t)(kseg0 + k0) * kRB;
     else
-      srcA = p.A + (int64_t)(tm * GROUPS + (wave >> 1)) * p.a_group_stride + (int64_t)k0 * (2 * kRB) + (wave & 1) * kRB;
+      srcA = p.A + (int64_t)(tm * GROUPS + (wave >> 1)) * p.a_group_stride + (int64_t)(kseg0 + k0) * (2 * kRB) + (wave & 1) * kRB;
     const unsigned char* srcB[PBW];
 #pragma unroll
     for (int u = 0; u < PBW; ++u) {
-      const int cb = min(tn * 8 + wave * PBW + u, p.ncb - 1);
-      srcB[u] = p.B + (int64_t)cb * p.b_rb_stride + (int64_t)k0 * kRB;
+      const int cb = min(tn * (GEO::TT / 32) + wave * PBW + u, p.ncb - 1);
+      srcB[u] = p.B + (int64_t)cb * p.b_rb_stride + (int64_t)(kseg0 + k0) * kRB;
     }
     unsigned char* const ldsA = smem + wave * kRB;
     unsigned char* const ldsB = smem + NPA * kFrag + wave * (PBW * kRB);
@@ -334,18 +366,14 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     if constexpr (PROF) {
       if (threadIdx.x == 0) prof_t0 = wall_clock64();
     }
-    f32x16 acc[4][2];
-    if (k0 > 0) {
-      // the head of this tile was computed by the workgroup 8 below: wait for its accumulators, continue its chain.
-      // The wait is bounded (a predecessor that never becomes resident must not hang the GPU) and LOUD: on expiry the
-      // workgroup ORs the caller's sticky status word and its pass's error word and continues from NaN accumulators, so
-      // the C-pass / plain-GEMM outputs of the tile are NaN (the Z-pass then takes its exact fallback for every element
-      // of the tile: correct values, slowly).  Once any workgroup of any launch has failed, later waits give up at once.
+    // Bounded, loud wait for a flag another workgroup raises (release) once its accumulators are in memory; uniform
+    // result.  On expiry: the caller's sticky status word and this pass's error word are set, `false` comes back.
+    auto wait_for = [&](unsigned* flag) -> bool {
       unsigned* const ok_word = reinterpret_cast<unsigned*>(smem + NST * STAGE + NW * 512);
       if (threadIdx.x == 0) {
         unsigned spins = 0, ok = 1u;
         const long long t_begin = wall_clock64();
-        while (__hip_atomic_load(p.flags + bid - 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           __builtin_amdgcn_s_sleep(8);
           if ((++spins & 63u) == 0u &&
               (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
@@ -359,14 +387,23 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
           __hip_atomic_store(p.flags + kErrWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(p.flags + bid - 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *ok_word = ok;
       }
       __syncthreads();
-      const bool handed_over = __builtin_amdgcn_readfirstlane(*ok_word) != 0u;
-      const f32x4* ip = reinterpret_cast<const f32x4*>(in_part) + (size_t)wave * 32 * 64 + lane;
+      return __builtin_amdgcn_readfirstlane(*ok_word) != 0u;     // (a main loop's barriers lie between two waits)
+    };
+    f32x16 acc[MI][2];
+    if (k0 > 0) {
+      // the head of this tile was computed by the workgroup 8 below: wait for its accumulators, continue its chain.
+      // The wait is bounded (a predecessor that never becomes resident must not hang the GPU) and LOUD: on expiry the
+      // workgroup ORs the caller's sticky status word and its pass's error word and continues from NaN accumulators, so
+      // the C-pass / plain-GEMM outputs of the tile are NaN (the Z-pass then takes its exact fallback for every element
+      // of the tile: correct values, slowly).  Once any workgroup of any launch has failed, later waits give up at once.
+      const bool handed_over = wait_for(p.flags + bid - 8);
+      const f32x4* ip = reinterpret_cast<const f32x4*>(in_part) + (size_t)wave * (GEO::ACC / 4) * 64 + lane;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -380,7 +417,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         }
     } else {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -399,7 +436,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     stage_in(0, 0);
     if constexpr (NST == 3) stage_in(1, (k0 + 1 < k1) ? 1 : 0);
     int st = 0;
-    bf16x8 a[4][3], b[2][3];
+    bf16x8 a[MI][3], b[2][3];
     if constexpr (STUDY == 3) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -408,9 +445,9 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[ni][q] = *reinterpret_cast<const bf16x8*>(smem + NPA * kFrag + wn * (2 * kRB) + lane16 + ni * kRB + q * kFrag);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[mi][q] = *reinterpret_cast<const bf16x8*>(smem + wm * (4 * kRB) + lane16 + mi * kRB + q * kFrag);
+        for (int q = 0; q < 3; ++q) a[mi][q] = *reinterpret_cast<const bf16x8*>(smem + wm * (MI * kRB) + lane16 + mi * kRB + q * kFrag);
     }
     for (int ks = k0; ks < k1; ++ks) {
       // This step's stage has landed (own loads: counted vmcnt -- loads retire in issue order, so with three stages the
@@ -423,7 +460,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       if constexpr (FULL || STUDY == 1) __builtin_amdgcn_s_barrier();
-      const unsigned char* sA = smem + st * STAGE + wm * (4 * kRB) + lane16;
+      const unsigned char* sA = smem + st * STAGE + wm * (MI * kRB) + lane16;
       const unsigned char* sB = smem + st * STAGE + NPA * kFrag + wn * (2 * kRB) + lane16;
       // The order below is pinned with sched_barrier: left to itself hipcc's scheduler flips between an order that
       // chains dependent MFMAs two apart behind piecemeal LDS waits and a good one on unrelated source edits (+-17 % on
@@ -453,6 +490,31 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
 #define X6_MM(mi, ni, q) acc[mi][ni] = TE_MFMA_BF16(a[mi][PA[q]], b[ni][PB[q]], acc[mi][ni])
 #define X6_RD_HEAD(r) X6_SB; X6_RDB(0, r); X6_RDA(0, r); X6_RDA(1, r); X6_SB
 #define X6_RD_TAIL(r) X6_SB; X6_RDB(1, r); X6_RDA(2, r); X6_RDA(3, r); X6_SB
+      if constexpr (MI == 2) {
+        // 64 x 64 wave tile: four blocks, 24 MFMAs and 12 fragment reads per step (three waves per SIMD cover the rest).
+        // Round r reads (b0 a0 a1 b1) of its plane pair; with I reads issued fragment n is present at lgkmcnt <= I - 1 - n.
+#define X6_RD4(r) X6_SB; X6_RDB(0, r); X6_RDA(0, r); X6_RDA(1, r); X6_RDB(1, r); X6_SB
+        X6_RD4(0);
+        X6_RD4(1);                                                   // 8 issued
+        if constexpr (FULL) stage_in((st + NST - 1) % NST, (ks + NST - 1 < k1) ? 1 : 0);
+        X6_WAIT(6); X6_MM(0, 0, 0);
+        X6_WAIT(5); X6_MM(1, 0, 0);
+        X6_WAIT(4); X6_MM(1, 1, 0); X6_MM(0, 1, 0);
+        X6_RD4(2);                                                   // 12 issued
+        X6_WAIT(6); X6_MM(0, 0, 1);
+        X6_WAIT(5); X6_MM(1, 0, 1);
+        X6_WAIT(4); X6_MM(1, 1, 1); X6_MM(0, 1, 1);
+        X6_WAIT(2); X6_MM(0, 0, 2);
+        X6_WAIT(1); X6_MM(1, 0, 2);
+        X6_WAIT(0); X6_MM(1, 1, 2); X6_MM(0, 1, 2);
+        X6_SB;
+#pragma unroll
+        for (int q6 = 3; q6 < 6; ++q6) {
+          X6_MM(0, 0, q6); X6_MM(1, 0, q6); X6_MM(1, 1, q6); X6_MM(0, 1, q6);
+          X6_SB;
+        }
+#undef X6_RD4
+      } else {
       X6_RD_HEAD(0);
       X6_RD_TAIL(0);                                                 // 6 issued
       // the next step's stage is requested before the first MFMA (a direct-to-LDS load between MFMAs costs issue slots)
@@ -483,6 +545,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         X6_MM(2, 1, q6); X6_MM(2, 0, q6); X6_MM(3, 0, q6); X6_MM(3, 1, q6);
         X6_SB;
       }
+      }
 #undef X6_SB
 #undef X6_RDB
 #undef X6_RDA
@@ -499,11 +562,11 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
         prof_loop += prof_t1 - prof_t0;
       }
     }
-    if (k1 < nks) {
-      // ---- publish the accumulators of a cut tile (guide: plain stores -> vmcnt(0) -> barrier -> release -> flag) ----
-      f32x4* op = reinterpret_cast<f32x4*>(my_part) + (size_t)wave * 32 * 64 + lane;
+    // ---- accumulators to memory + flag (guide: plain stores -> vmcnt(0) -> barrier -> release -> flag) ----
+    auto publish = [&](float* dst, unsigned* flag) __attribute__((always_inline)) {
+      f32x4* op = reinterpret_cast<f32x4*>(dst) + (size_t)wave * (GEO::ACC / 4) * 64 + lane;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -521,15 +584,46 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!p.drop_handover) __hip_atomic_store(p.flags + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!p.drop_handover) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (PROF) prof_pub += wall_clock64() - prof_t1;
       }
+    };
+    if (k1 < nks) {            // a cut work item: the workgroup 8 above continues this chain
+      publish(my_part, p.flags + bid);
       continue;
+    }
+    if constexpr (KSPLIT == 2) {
+      // Two K segments per tile, each its own k-ordered chain, summed once: out = chain(segment 0) + chain(segment 1),
+      // whatever the schedule.  Segment 0 leaves its accumulators in seg_part[tile]; segment 1 -- a later work item of the
+      // same XCD, i.e. a HIGHER workgroup slot running at the same time -- waits for them here, at its END.
+      float* const sp = p.seg_part + (size_t)tile * GEO::THREADS * GEO::ACC;
+      unsigned* const sflag = p.seg_flags + tile;
+      if (seg == 0) {
+        publish(sp, sflag);
+        __syncthreads();
+        continue;
+      }
+      const bool got = wait_for(sflag);
+      const f32x4* ip = reinterpret_cast<const f32x4*>(sp) + (size_t)wave * (GEO::ACC / 4) * 64 + lane;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 v = ip[c * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][ni][4 * c + e] = got ? v[e] + acc[mi][ni][4 * c + e] : __builtin_nanf("");
+          }
+          ip += 4 * 64;
+          asm volatile("" : "+v"(ip));
+          __builtin_amdgcn_sched_barrier(0);      // one block (16 registers) of segment 0 in flight at a time: the
+        }                                         // accumulators are live here, a batch of all 32 loads would spill
     }
 
     if constexpr (!EPI) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
       __syncthreads();
@@ -554,7 +648,7 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       float f[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int cb = tn * 8 + wn * 2 + ni;
+        const int cb = tn * (GEO::TT / 32) + wn * 2 + ni;
         const int64_t t = (int64_t)cb * 32 + tc;
         blk[ni] = cb < p.ncb;
         live[ni] = t < p.T;
@@ -564,15 +658,17 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
       // the wave's 128 bias values go through a private 512-B LDS slot: reading them back counts on lgkmcnt, so no wait
       // for a bias value drains the prefetched R / Y loads of the next block
       float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 128;
-      if (lane < 32) {
+      if (lane < MI * 8) {
         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (4 * WM) + wm * 4) * 32 + lane * 4);
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (NWM * MI) + wm * MI) * 32 + lane * 4);
         *reinterpret_cast<f32x4*>(bias_lds + lane * 4) = bv;
       }
-      f32x4 r4[2][4], y4[2][4];
+      // (128 x 128 geometry: three waves per SIMD cover the load latency, and 168 VGPRs do not hold a second buffer)
+      constexpr int NBUF = (MI == 4) ? 2 : 1;
+      f32x4 r4[NBUF][4], y4[NBUF][4];
       auto load_block = [&](int bi, int buf) __attribute__((always_inline)) {
-        const int ni = bi >> 2, mi = bi & 3;
-        const int j0 = (tm * (4 * WM) + wm * 4 + mi) * 32;
+        const int ni = bi / MI, mi = bi % MI;
+        const int j0 = (tm * (NWM * MI) + wm * MI + mi) * 32;
         const float* Rrow = p.R + tl[ni] * p.out_f + j0 + 4 * h;
         const float* Yrow = p.Y + tl[ni] * p.out_f + j0 + 4 * h;
 #pragma unroll
@@ -581,13 +677,17 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
           y4[buf][g] = *reinterpret_cast<const f32x4*>(Yrow + 8 * g);
         }
       };
-      load_block(0, 0);
+      if constexpr (NBUF == 2) load_block(0, 0);
 #pragma unroll
-      for (int bi = 0; bi < 8; ++bi) {
-        const int ni = bi >> 2, mi = bi & 3, buf = bi & 1;
-        const int cb = tn * 8 + wn * 2 + ni;
-        const int j0 = (tm * (4 * WM) + wm * 4 + mi) * 32;
-        if (bi + 1 < 8) load_block(bi + 1, buf ^ 1);      // in flight during this block's arithmetic
+      for (int bi = 0; bi < 2 * MI; ++bi) {
+        const int ni = bi / MI, mi = bi % MI, buf = bi % NBUF;
+        const int cb = tn * (GEO::TT / 32) + wn * 2 + ni;
+        const int j0 = (tm * (NWM * MI) + wm * MI + mi) * 32;
+        if constexpr (NBUF == 2) {
+          if (bi + 1 < 2 * MI) load_block(bi + 1, buf ^ 1);      // in flight during this block's arithmetic
+        } else {
+          load_block(bi, 0);
+        }
         unsigned w[4][3][2];                       // [g][plane][dword]: four bf16 of one plane = weight rows 8g+4h+0..3
         unsigned bad = 0;                          // elements whose Z needs the cancellation fallback
 #pragma unroll
@@ -661,17 +761,17 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
     } else if constexpr (MODE == MODE_G) {
       // plain product: out[t][m] = acc + bias[m] (fp32 row-major [T, M]); the wave's 128 bias values through its LDS slot
       float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 128;
-      if (lane < 32) {
+      if (lane < MI * 8) {
         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (4 * WM) + wm * 4) * 32 + lane * 4);
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (NWM * MI) + wm * MI) * 32 + lane * 4);
         *reinterpret_cast<f32x4*>(bias_lds + lane * 4) = bv;
       }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int64_t t = ((int64_t)tn * 8 + wn * 2 + ni) * 32 + tc;
-        float* orow = p.out + (t < p.T ? t : 0) * p.out_f + (tm * (4 * WM) + wm * 4) * 32 + 4 * h;
+        const int64_t t = ((int64_t)tn * (GEO::TT / 32) + wn * 2 + ni) * 32 + tc;
+        float* orow = p.out + (t < p.T ? t : 0) * p.out_f + (tm * (NWM * MI) + wm * MI) * 32 + 4 * h;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + mi * 32 + 8 * g + 4 * h);
@@ -682,17 +782,17 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
           }
       }
     } else {
-      f32x4 x4[2][2][4];
+      f32x4 x4[2][MI / 2][4];
       int64_t tt[2];
       bool live[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int64_t t = ((int64_t)tn * 8 + wn * 2 + ni) * 32 + tc;
+        const int64_t t = ((int64_t)tn * (GEO::TT / 32) + wn * 2 + ni) * 32 + tc;
         live[ni] = t < p.T;
         tt[ni] = live[ni] ? t : p.T - 1;
 #pragma unroll
-        for (int il = 0; il < 2; ++il) {
-          const float* xr = p.X + tt[ni] * p.in_f + (tm * (2 * WM) + wm * 2 + il) * 32 + 4 * h;
+        for (int il = 0; il < MI / 2; ++il) {
+          const float* xr = p.X + tt[ni] * p.in_f + (tm * (NWM * MI / 2) + wm * (MI / 2) + il) * 32 + 4 * h;
 #pragma unroll
           for (int g = 0; g < 4; ++g) x4[ni][il][g] = *reinterpret_cast<const f32x4*>(xr + 8 * g);
         }
@@ -700,8 +800,8 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int il = 0; il < 2; ++il) {
-          float* orow = p.out + tt[ni] * p.in_f + (tm * (2 * WM) + wm * 2 + il) * 32 + 4 * h;
+        for (int il = 0; il < MI / 2; ++il) {
+          float* orow = p.out + tt[ni] * p.in_f + (tm * (NWM * MI / 2) + wm * (MI / 2) + il) * 32 + 4 * h;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             f32x4 o;
@@ -736,7 +836,22 @@ __global__ __launch_bounds__(256 * WM, 2) void x6_kernel(const X6Params p) {
 inline size_t planes_bytes(int64_t rows, int64_t K) {
   return (size_t)te_ceil_div(rows, 32) * 32 * (size_t)K * 6;
 }
-constexpr size_t kPartialBytes = (size_t)512 * 256 * 128 * 4;       // grid x threads x 128 floats, both geometries: 64 MiB
+// Fixed K split (the same for every tile geometry, batch size and schedule: a property of the layer's shape only, so
+// results stay bitwise batch-invariant and geometry-invariant).  Products with a long K and few weight rows -- out_f = 768
+// against K = 2304 / 3072: fc2's forward, the input gradients of qkv and fc1, fc2's Z-pass -- are 150 tiles of 256 x 256
+// for 256 CUs, and a tile is a SEQUENTIAL chain of K / 16 steps however it is scheduled: 144-192 steps of ~1.9 us were the
+// floor of those launches.  Two chains per output halve the floor and double the work items.
+inline int kseg_rule(int64_t K, int64_t rows_w) { return (K >= 1536 && rows_w <= 768 && (K / 16) % 2 == 0) ? 2 : 1; }
+inline size_t seg_part_bytes(int64_t T, int64_t K, int64_t rows_w) {       // accumulators of segment 0, any geometry
+  return kseg_rule(K, rows_w) == 2 ? te_align_up((size_t)te_ceil_div(T, 256) * 256 * (size_t)rows_w * 4, 256) : 0;
+}
+inline size_t seg_flag_words(int64_t T, int64_t K, int64_t rows_w) {       // one per tile of the smallest geometry, x 1024
+  return kseg_rule(K, rows_w) == 2 ? te_align_up((size_t)te_ceil_div(T, 128) * (size_t)(rows_w / 128), 1024) : 0;
+}
+inline size_t seg_region_bytes(int64_t T, int64_t K, int64_t rows_w) {
+  return seg_part_bytes(T, K, rows_w) + seg_flag_words(T, K, rows_w) * 4;
+}
+constexpr size_t kPartialBytes = (size_t)512 * 256 * 128 * 4;       // grid x threads x accumulators: 64 MiB covers every geometry
 constexpr double kWholeTileSlack = 1.15;                          // whole tiles if ceil(r) <= 1.15 r (launch_x6)
 constexpr size_t kFlagBytes = 65536;                                 // 512 flags + the error word (+ study time stamps), per pass
 
@@ -759,38 +874,74 @@ inline long long spin_ticks_for_current_device() {
   return cached[dev];
 }
 
-template <int WM, int MODE, int STUDY = 0, int NST = 2>
+template <int WM, int MODE, int STUDY = 0, int NST = 2, int KSPLIT = 1>
 int launch_x6(const X6Params& p, hipStream_t stream) {
-  constexpr int NP = 12 * WM + 24;
-  constexpr int lds = NST * NP * kFrag + 4 * WM * 512 + 16;      // stages + one 512-B bias slot per wave + the hand-over word
-  static_assert(lds <= 160 * 1024, "LDS of one workgroup");
-  auto kern = x6_kernel<WM, MODE, STUDY, NST>;
+  using GEO = X6Geo<WM>;
+  constexpr int NP = GEO::NPA + GEO::NPB;
+  constexpr int lds = NST * NP * kFrag + GEO::NW * 512 + 16;      // stages + one 512-B bias slot per wave + the hand-over word
+  static_assert(lds * (WM == 0 ? 3 : WM == 1 ? 2 : 1) <= 160 * 1024, "LDS of the workgroups of one CU");
+  static_assert((size_t)8 * GEO::MAX_SPX * GEO::THREADS * GEO::ACC * 4 <= kPartialBytes && 8 * GEO::MAX_SPX < kErrWord, "workspace");
+  auto kern = x6_kernel<WM, MODE, STUDY, NST, KSPLIT>;
   // an attribute of the code object ON THE CURRENT DEVICE: set per launch (idempotent, no data-path state)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return (int)e;
-  const int64_t tiles = (int64_t)p.ntm * p.ntn;
-  const int max_spx = p.small_grid ? 2 : (WM == 2) ? 32 : 64;
+  X6Params q = p;
+  q.ksplit = KSPLIT;
+  q.ntm = p.rows_w / GEO::TM;
+  q.ntn = (int)te_ceil_div(p.T, GEO::TT);
+  const int64_t tiles = (int64_t)q.ntm * q.ntn * q.ksplit;      // work items
+  const int max_spx = p.small_grid ? 2 : GEO::MAX_SPX;
   const int spx = (int)std::min<int64_t>(max_spx, std::max<int64_t>(1, te_ceil_div(tiles, 8)));
   // Stream-K or whole tiles?  With equal (tile, k) ranges the workgroups of an XCD sit at different k offsets of their
   // tiles and nothing one of them fetches is still in the 4 MB L2 when its neighbour needs it; cut at tile boundaries
   // they run a round in k lock-step on shared operand panels and a K16 step takes 1.9 instead of 2.1-2.6 us (measured,
   // profiles/r03_x6_whole_tiles.log) -- which pays as long as the last round is nearly full.  r = tiles per workgroup;
   // whole tiles cost ceil(r) rounds.  Either way every output is the same k-ordered chain: results do not change.
-  X6Params q = p;
   const double r = (double)tiles / (8.0 * spx);
-  if (!q.whole_tiles_forced) q.whole_tiles = (std::ceil(r) <= kWholeTileSlack * r) ? 1 : 0;
+  if (!q.whole_tiles_forced) q.whole_tiles = (std::ceil(r) <= kWholeTileSlack * r && !p.small_grid) ? 1 : 0;
   if (!q.status) q.status = q.flags + kErrWord;
   q.spin_ticks = spin_ticks_for_current_device();
-  kern<<<dim3(8 * spx), dim3(256 * WM), lds, stream>>>(q);
+  kern<<<dim3(8 * spx), dim3(GEO::THREADS), lds, stream>>>(q);
   return TE_OK;
 }
 
-// WM = 2 runs three LDS stages (148 KiB, one workgroup per CU either way) unless the caller pins two; WM = 1 keeps two
-// (74 KiB: two workgroups per CU)
+// Two LDS stages everywhere; TE_X6_STAGES_3 (measurement) runs the 256 x 256 geometry with three (prefetch distance 2 behind
+// a raw barrier, 148 KiB).  Measured on the MI355X, ViT-B/16 batch 64 (profiles/r04_x6_variants.log): Z-pass and plain
+// products +-0.5 %, C-pass 7 % SLOWER -- a fill that misses the L2 is not what the loop waits for; the third stage's
+// traffic in flight costs more than its latency cover buys.
 template <int MODE>
-int launch_x6_mode(int wm, bool two_stages, const X6Params& p, hipStream_t stream) {
-  if (wm == 2) return two_stages ? launch_x6<2, MODE, 0, 2>(p, stream) : launch_x6<2, MODE, 0, 3>(p, stream);
-  return launch_x6<1, MODE, 0, 2>(p, stream);
+int launch_x6_mode(int wm, bool three_stages, const X6Params& p, hipStream_t stream) {
+  if constexpr (MODE != MODE_C) {
+    if (p.seg_part && p.seg_flags && kseg_rule((int64_t)p.nks * 16, p.rows_w) == 2) {
+      if (wm == 2) return launch_x6<2, MODE, 0, 2, 2>(p, stream);
+      if (wm == 1) return launch_x6<1, MODE, 0, 2, 2>(p, stream);
+      return launch_x6<0, MODE, 0, 2, 2>(p, stream);
+    }
+  }
+  if (wm == 2) return three_stages ? launch_x6<2, MODE, 0, 3>(p, stream) : launch_x6<2, MODE, 0, 2>(p, stream);
+  if (wm == 1) return launch_x6<1, MODE, 0, 2>(p, stream);
+  return launch_x6<0, MODE, 0, 2>(p, stream);
+}
+
+// Tile geometry of a launch (2 / 1 / 0 = 256 x 256 / 128 x 256 / 128 x 128; the result does not depend on it, bit for bit).
+// wm_max = the largest geometry the feature counts divide into; rows_w = weight-side rows; pin = TE_X6_TILE_* or 0.
+// small_ok: the launch may use the 128 x 128 geometry (Z-pass, plain products; the C-pass never gains from it).
+// Measured per launch on the MI355X (profiles/r04_x6_geometry.log; ViT-B/16 batch 64, BERT-512 batch 32, ViT-L/16-384 batch
+// 32): out_f = 768 at T = 12 608 / 16 384 (300 / 384 tiles of 128 x 256) runs 8-15 % faster on 128 x 128 tiles (Z-pass
+// 143 -> 121 us and 431 -> 368 us, products 119 -> 106, 401 -> 360, 313 -> 280, 408 -> 368 us); out_f = 1024 at T = 18 464
+// (584 tiles) is 10 % faster on 128 x 256.
+inline int choose_geo(int wm_max, int64_t T, int64_t rows_w, int pin, int min_tiles_256 = 256, bool small_ok = false,
+                      int ksplit = 1) {
+  if (pin == TE_X6_TILE_128) return 1;
+  if (pin == TE_X6_TILE_256) return wm_max;
+  if (pin == TE_X6_TILE_128x128) return 0;
+  const int64_t t256 = te_ceil_div(T, 256);
+  // 256-row tiles (one 512-thread workgroup per CU, every operand byte staged once for eight waves) where that gives
+  // every CU a tile ...
+  if (wm_max == 2 && t256 * (rows_w / 256) * ksplit >= min_tiles_256) return 2;       // (work items: tiles x K segments)
+  // ... 128 x 256 (two workgroups per CU) while there are at least ~1.75 tiles per CU, else 128 x 128 (three per CU)
+  if (small_ok && t256 * (rows_w / 128) * ksplit < 448) return 0;
+  return 1;
 }
 
 }  // namespace
@@ -877,15 +1028,14 @@ extern "C" int te_linear_x6_split_dual_f32(const float* A, int64_t rows, int64_t
 
 extern "C" size_t te_gemm_x6_workspace_bytes(int64_t T, int64_t K, int64_t M) {
   if (!te_gemm_x6_supported(T, K, M)) return 0;
-  return te_align_up(planes_bytes(T, K), 256) + kPartialBytes + kFlagBytes;
+  return te_align_up(planes_bytes(T, K), 256) + kPartialBytes + kFlagBytes + seg_region_bytes(T, K, M);
 }
 
 extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* w_planes, const float* bias, float* out,
                               int64_t T, int64_t K, int64_t M, int flags, unsigned* status, void* ws, size_t ws_bytes,
                               te_stream_t stream_) {
   if ((!X && !x_planes) || !w_planes || !out) return TE_ERR_INVALID_ARG;
-  if ((flags & ~(3 | TE_X6_STAGES_2 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0 || (flags & 3) == 3)
-    return TE_ERR_INVALID_ARG;
+  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
   if (!te_gemm_x6_supported(T, K, M)) return TE_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < te_gemm_x6_workspace_bytes(T, K, M) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
   if ((X && !te_aligned16(X)) || !te_aligned16(out) || !te_aligned16(w_planes) || (bias && !te_aligned16(bias)) ||
@@ -898,16 +1048,21 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   float* partial = (float*)q;
   q += kPartialBytes;
   unsigned* flag_words = (unsigned*)q;
+  q += kFlagBytes;
   zero_words_kernel<<<dim3(kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
+  float* seg_part = nullptr;
+  unsigned* seg_flags = nullptr;
+  if (kseg_rule(K, M) == 2) {
+    seg_part = (float*)q;
+    seg_flags = (unsigned*)(q + seg_part_bytes(T, K, M));
+    zero_words_kernel<<<dim3((unsigned)(seg_flag_words(T, K, M) / 1024)), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(seg_flags));
+  }
   if (!x_planes) {
     int rc = te_linear_x6_split_matrix_f32(X, T, K, 0, Xs, planes_bytes(T, K), stream_);
     if (rc != TE_OK) return rc;
     x_planes = Xs;
   }
-  int wm = (M % 256 == 0) ? 2 : 1;
-  if (wm == 2 && te_ceil_div(T, kTileT) * (M / 256) < 192) wm = 1;
-  if ((flags & 3) == TE_X6_TILE_128) wm = 1;
-  if ((flags & 3) == TE_X6_TILE_256 && M % 256 == 0) wm = 2;
+  int wm = choose_geo((M % 256 == 0) ? 2 : 1, T, M, flags & 3, 192, true, kseg_rule(K, M));
   X6Params p{};
   p.status = status;
   p.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
@@ -920,9 +1075,11 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   p.in_f = (int)K;
   p.out_f = (int)M;
   p.ncb = (int)te_ceil_div(T, 32);
-  p.ntn = (int)te_ceil_div(T, kTileT);
+  p.rows_w = (int)M;
   p.partial = partial;
   p.flags = flag_words;
+  p.seg_part = seg_part;
+  p.seg_flags = seg_flags;
   p.bias = bias;
   p.out = out;
   p.A = (const unsigned char*)w_planes;
@@ -930,19 +1087,15 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   p.nks = (int)(K / 16);
   p.a_group_stride = (int64_t)p.nks * kRB;
   p.b_rb_stride = (int64_t)p.nks * kRB;
-  p.ntm = (int)(M / (128 * wm));
   int rc;
 #ifdef TE_X6_STUDY
   // study builds (benchmarks/x6_gemm_bench.py): TE_X6_G_WM pins the tile geometry, TE_X6_G_PROF=1 runs the time-stamped kernel
-  if (const char* e = getenv("TE_X6_G_WM")) {
-    wm = (atoi(e) == 2 && M % 256 == 0) ? 2 : 1;
-    p.ntm = (int)(M / (128 * wm));
-  }
+  if (const char* e = getenv("TE_X6_G_WM")) wm = (atoi(e) == 2 && M % 256 == 0) ? 2 : 1;
   const char* pe = getenv("TE_X6_G_PROF");
   if (pe && atoi(pe) == 1) rc = (wm == 2) ? launch_x6<2, MODE_G, 5>(p, stream) : launch_x6<1, MODE_G, 5>(p, stream);
   else
 #endif
-  rc = launch_x6_mode<MODE_G>(wm, (flags & TE_X6_STAGES_2) != 0, p, stream);
+  rc = launch_x6_mode<MODE_G>(wm, (flags & TE_X6_STAGES_3) != 0, p, stream);
   if (rc != TE_OK) return rc;
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
@@ -951,7 +1104,8 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
 // workspace: |X| planes, S planes, the accumulators of cut tiles, flags (Z-pass, C-pass)
 extern "C" size_t te_linear_relprop_x6_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f) {
   if (!te_linear_relprop_x6_supported(T, in_f, out_f)) return 0;
-  return te_align_up(planes_bytes(T, in_f), 256) + te_align_up(planes_bytes(T, out_f), 256) + kPartialBytes + 2 * kFlagBytes;
+  return te_align_up(planes_bytes(T, in_f), 256) + te_align_up(planes_bytes(T, out_f), 256) + kPartialBytes + 2 * kFlagBytes +
+         seg_region_bytes(T, in_f, out_f);
 }
 
 extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
@@ -976,6 +1130,8 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   float* partial = (float*)q;
   q += kPartialBytes;
   unsigned* flag_words = (unsigned*)q;
+  q += 2 * kFlagBytes;
+  unsigned char* const seg_region = q;          // shared by the two passes (they run one after the other)
   const unsigned char* wz = (const unsigned char*)w_planes;
   const unsigned char* wc = wz + te_align_up(planes_bytes(out_f, in_f), 256);
 
@@ -994,23 +1150,16 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   // Tile geometry per pass (the result does not depend on it, bit for bit): 256 weight rows / one 512-thread workgroup per
   // CU where that gives every CU at least one tile, else 128 rows / two 256-thread workgroups per CU.
   const int wm_max = pick_wm(in_f, out_f);
-  const int64_t ntn_ = te_ceil_div(T, kTileT);
-  int wm_z = (wm_max == 2 && ntn_ * (out_f / 256) >= 256) ? 2 : 1;
-  int wm_c = (wm_max == 2 && ntn_ * (in_f / 128) >= 256) ? 2 : 1;
-  if ((flags & 3) == TE_X6_TILE_128) wm_z = wm_c = 1;
-  if ((flags & 3) == TE_X6_TILE_256) wm_z = wm_c = wm_max;
-  if (((flags >> 10) & 3) == TE_X6_TILE_128) wm_z = 1;              // per-pass pins (measurement)
-  if (((flags >> 10) & 3) == TE_X6_TILE_256) wm_z = wm_max;
-  if (((flags >> 12) & 3) == TE_X6_TILE_128) wm_c = 1;
-  if (((flags >> 12) & 3) == TE_X6_TILE_256) wm_c = wm_max;
+  const int pin_z = ((flags >> TE_X6_TILE_Z_SHIFT) & 3) ? ((flags >> TE_X6_TILE_Z_SHIFT) & 3) : (flags & 3);      // per-pass pins win
+  const int pin_c = ((flags >> TE_X6_TILE_C_SHIFT) & 3) ? ((flags >> TE_X6_TILE_C_SHIFT) & 3) : (flags & 3);
+  const int wm_z = choose_geo(wm_max, T, out_f, pin_z, 256, true, kseg_rule(in_f, out_f));
+  const int wm_c = choose_geo(wm_max, T, 2 * in_f, pin_c);
 #ifdef TE_X6_STUDY
   const int study = (flags >> 5) & 7;      // study builds: run ablation `study` of the main loop instead
   flags &= ~0xe0;
 #endif
-  if ((flags & ~(0x1f | TE_X6_STAGES_2 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0 || (flags & 3) == 3 ||
-      ((flags >> 10) & 3) == 3 || ((flags >> 12) & 3) == 3)
-    return TE_ERR_INVALID_ARG;
-  const bool two_stages = (flags & TE_X6_STAGES_2) != 0;
+  if ((flags & ~(0x1f | TE_X6_STAGES_3 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0) return TE_ERR_INVALID_ARG;
+  const bool three_stages = (flags & TE_X6_STAGES_3) != 0;
   int wm = 0;
   X6Params p{};
 #ifdef TE_X6_STUDY
@@ -1021,7 +1170,6 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   p.in_f = (int)in_f;
   p.out_f = (int)out_f;
   p.ncb = (int)te_ceil_div(T, 32);
-  p.ntn = (int)te_ceil_div(T, kTileT);
   p.partial = partial;
   p.R = R;
   p.Y = Y;
@@ -1044,8 +1192,15 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     p.a_group_stride = (int64_t)p.nks * kRB;
     p.b_rb_stride = (int64_t)p.nks * kRB;
     wm = wm_z;
-    p.ntm = (int)(out_f / (128 * wm));
+    p.rows_w = (int)out_f;
     p.flags = flag_words;
+    p.seg_part = nullptr, p.seg_flags = nullptr;
+    if (kseg_rule(in_f, out_f) == 2) {
+      p.seg_part = (float*)seg_region;
+      p.seg_flags = (unsigned*)(seg_region + seg_part_bytes(T, in_f, out_f));
+      zero_words_kernel<<<dim3((unsigned)(seg_flag_words(T, in_f, out_f) / 1024)), dim3(256), 0, stream>>>(
+          reinterpret_cast<u32x4*>(p.seg_flags));
+    }
 #ifdef TE_X6_STUDY
     if (wm == 2 && study == 1) rc = launch_x6<2, MODE_Z, 1>(p, stream);
     else if (wm == 2 && study == 2) rc = launch_x6<2, MODE_Z, 2>(p, stream);
@@ -1056,7 +1211,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     else if (wm == 1 && study == 5) rc = launch_x6<1, MODE_Z, 5>(p, stream);
     else
 #endif
-    rc = launch_x6_mode<MODE_Z>(wm, two_stages, p, stream);
+    rc = launch_x6_mode<MODE_Z>(wm, three_stages, p, stream);
     if (rc != TE_OK) return rc;
   }
   if (phases & TE_X6_PHASE_C) {   // C-pass: D[(i, +-)][t] = sum_j W+-[j][i] S[t][j]
@@ -1066,8 +1221,9 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     p.a_group_stride = (int64_t)p.nks * 2 * kRB;
     p.b_rb_stride = (int64_t)p.nks * kRB;
     wm = wm_c;
-    p.ntm = (int)(in_f / (64 * wm));
+    p.rows_w = (int)(2 * in_f);
     p.flags = flag_words + kFlagBytes / 4;
+    p.seg_part = nullptr, p.seg_flags = nullptr;       // (the C-pass has 2 in_f weight rows: never a launch the split helps)
 #ifdef TE_X6_STUDY
     if (wm == 2 && study == 1) rc = launch_x6<2, MODE_C, 1>(p, stream);
     else if (wm == 2 && study == 2) rc = launch_x6<2, MODE_C, 2>(p, stream);
@@ -1078,7 +1234,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     else if (wm == 1 && study == 5) rc = launch_x6<1, MODE_C, 5>(p, stream);
     else
 #endif
-    rc = launch_x6_mode<MODE_C>(wm, two_stages, p, stream);
+    rc = launch_x6_mode<MODE_C>(wm, three_stages, p, stream);
     if (rc != TE_OK) return rc;
   }
   TE_RETURN_IF_LAUNCH_FAILED();

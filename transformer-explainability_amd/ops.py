@@ -119,9 +119,9 @@ USE_FORWARD_PRODUCTS = True
 USE_LINEAR_X6 = os.environ.get("TE_LINEAR_X6", "1") not in ("", "0")
 X6_CHECK = False     # tests: synchronise after every x6 rule and raise if a bounded hand-over wait expired
 X6_TILE = 0          # te_relprop.h TE_X6_TILE_*: 0 auto, 1 = 128-row weight tiles (measurement knob; results are identical)
-X6_FLAGS = 0         # extra te_relprop.h flag bits for every x6 launch (TE_X6_STAGES_2, per-pass tile pins, the test hook)
+X6_FLAGS = int(os.environ.get("TE_X6_FLAGS", "0"), 0)   # extra te_relprop.h flag bits for every x6 launch (TE_X6_STAGES_3, per-pass tile pins, test hooks)
 TE_X6_PHASE_SPLIT, TE_X6_PHASE_Z, TE_X6_PHASE_C = 4, 8, 16
-TE_X6_STAGES_2, TE_X6_TEST_DROP_HANDOVER, TE_X6_TILE_Z_SHIFT, TE_X6_TILE_C_SHIFT, TE_X6_TEST_SMALL_GRID = 0x100, 0x200, 10, 12, 0x4000
+TE_X6_STAGES_3, TE_X6_TEST_DROP_HANDOVER, TE_X6_TILE_Z_SHIFT, TE_X6_TILE_C_SHIFT, TE_X6_TEST_SMALL_GRID = 0x100, 0x200, 10, 12, 0x4000
 
 # A workgroup of an x6 kernel that continues a tile another workgroup started waits for that one's accumulators; the wait
 # is bounded, and a wait that expires must never yield a plausible-looking map (VERDICT r3 / ADVICE r3).  Every x6 launch
@@ -487,8 +487,9 @@ def _heads(t: Tensor, H: int):
 def attention_forward_qkv(q: Tensor, k: Tensor, v: Tensor, num_heads: int, scale: float,
                           mask: Optional[Tensor] = None, want_z: bool = True, want_x: bool = False):
     """q, k, v: [B,N,C] views ('b n (h d)', e.g. thirds of the fused ViT activation or BERT's three Linear outputs);
-    mask [B,N] additive or None -> (out [B,N,C], attn [B,H,N,N], z_qk [B,H,N,N] unscaled or None, x = z_qk * scale + mask
-    [B,H,N,N] or None).  csrc/te_attn_long.hip."""
+    mask [B,N] additive or None -> (out [B,N,C], attn [B,H,N,N], z_qk [B,H,N,N] unscaled or None, x = z_qk * scale
+    [B,H,N,N] or None: the scaled scores BEFORE the mask is added, i.e. the first operand of BERT's Add module).
+    csrc/te_attn_long.hip."""
     B, N, C = q.shape
     H, D = num_heads, C // num_heads
     dev = q.device
