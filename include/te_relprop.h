@@ -315,6 +315,24 @@ int te_linear_relprop_x6_f32(const float* R, const float* r_scale, int64_t r_sca
                              size_t ws_bytes, te_stream_t stream);
 int te_linear_relprop_x6_check(const void* ws, int64_t T, int64_t in_f, int64_t out_f, te_stream_t stream);
 
+/* The same rule for EVERY variant and alpha on the x6 kernels (csrc/te_linear_x6.hip): variant TE_VARIANT_LRP =
+ * modules/layers_lrp.py:188-211 (S1 = sd(R, X+ W+^T), S2 = sd(R, X- W-^T), separate denominators), and the inhibitor half
+ * alpha * f(pw, nw, px, nx) - beta * f(nw, pw, px, nx), beta = alpha - 1, of both variants (layers_ours.py:225-228).
+ *   variant ours: w_planes as above, Y (the forward output) required; x_abs_planes optional (the |X| planes).
+ *   variant lrp : w_planes_lrp from te_linear_x6_prepare_weights_lrp_f32 (P3 planes of max(W,0), min(W,0) and of their
+ *                 transposes); in_f % 128 == 0; Y, bias, w_planes unused (may be NULL).
+ * flags: TE_X6_TILE_* | TE_X6_STAGES_3 | test hooks; status as te_linear_relprop_x6_f32. */
+int te_linear_relprop_x6_general_supported(int64_t T, int64_t in_f, int64_t out_f, int variant);
+size_t te_linear_x6_weight_planes_lrp_bytes(int64_t in_f, int64_t out_f);
+int te_linear_x6_prepare_weights_lrp_f32(const float* W, int64_t in_f, int64_t out_f, void* planes, size_t planes_bytes,
+                                         te_stream_t stream);
+size_t te_linear_relprop_x6_general_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f, int variant);
+int te_linear_relprop_x6_general_f32(const float* R, const float* r_scale, int64_t r_scale_stride, int64_t rows_per_sample,
+                                     const float* X, const float* W, const void* w_planes, const void* w_planes_lrp,
+                                     const void* x_abs_planes, const float* Y, const float* bias, float* out,
+                                     int64_t T, int64_t in_f, int64_t out_f, float alpha, int variant, int flags,
+                                     unsigned* status, void* ws, size_t ws_bytes, te_stream_t stream);
+
 /* The plain fp32 product on the same kernels (the forward output and the input gradient of a Linear layer,
  * modules/layers_ours.py:207 = nn.Linear): out [T, M] = X [T, K] . W^T + bias [M] with W given as signed P3 planes of an
  * [M, K] matrix.  te_linear_x6_split_matrix_f32 builds such planes from a row-major [rows, K] matrix (transposed = 0) or

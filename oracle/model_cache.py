@@ -34,10 +34,18 @@ def vit_cache_from_model(model):
 
 
 def bert_cache_from_model(model):
+    import math
     layers = []
     for lay in model.bert.encoder.layer:
         sa = lay.attention.self
         masked = sa.attention_mask is not None
+        # The first operand of the mask Add (BERT.py:339-342: the scaled scores BEFORE the mask is added) is RECOMPUTED here
+        # from the cached q k^T instead of read from the module's own add.X[0]: a producer that caches the wrong tensor
+        # there (scores + mask, i.e. the mask twice in Add.relprop's denominator) then disagrees with the oracle.
+        zqk = _cpu(getattr(sa.matmul1, "Y", None))
+        x0 = None
+        if masked:
+            x0 = zqk / math.sqrt(sa.attention_head_size) if zqk is not None else _cpu(sa.add.X[0])
         layers.append({
             "out_add_x0": _cpu(lay.output.add.X[0]), "out_add_x1": _cpu(lay.output.add.X[1]),
             "out_dense_x": _cpu(lay.output.dense.X), "out_dense_w": _cpu(lay.output.dense.weight),
@@ -47,12 +55,12 @@ def bert_cache_from_model(model):
             "att_dense_x": _cpu(lay.attention.output.dense.X), "att_dense_w": _cpu(lay.attention.output.dense.weight),
             "probs": _cpu(sa.get_attn()), "attn_grad": _cpu(sa.get_attn_gradients()),
             "q": _cpu(sa.query.Y), "k": _cpu(sa.key.Y), "v": _cpu(sa.value.Y),
-            "mask_add_x0": _cpu(sa.add.X[0]) if masked else None,
+            "mask_add_x0": x0,
             "ext_mask": _cpu(sa.add.X[1]) if masked else None,
             "q_x": _cpu(sa.query.X), "q_w": _cpu(sa.query.weight), "k_x": _cpu(sa.key.X), "k_w": _cpu(sa.key.weight),
             "v_x": _cpu(sa.value.X), "v_w": _cpu(sa.value.weight),
             "self_clone_x": _cpu(sa.clone.X), "att_clone_x": _cpu(lay.attention.clone.X),
-            "z_qk": _cpu(getattr(sa.matmul1, "Y", None)), "z_av": _cpu(getattr(sa.matmul2, "Y", None))})
+            "z_qk": zqk, "z_av": _cpu(getattr(sa.matmul2, "Y", None))})
     return {"cls_x": _cpu(model.classifier.X), "cls_w": _cpu(model.classifier.weight),
             "pool_dense_x": _cpu(model.bert.pooler.dense.X), "pool_dense_w": _cpu(model.bert.pooler.dense.weight),
             "pool_x": _cpu(model.bert.pooler.pool.X), "layers": layers}

@@ -14,3 +14,5 @@ for k in d["roofline"]["kernels"][:12]:
     print("   ", k["name"], k["launches"], k["avg_us"], k["frac"])
 PY
 grep "probe linear" gpurun_out/t8_bench_2.err | cut -c18-150
+timeout 600 python -m pytest tests/test_gpu_models.py tests/test_gpu_producers.py -x -q -m gpu -k "soft_mask or bert_layout or bert_tiny or bert_base" > gpurun_out/t8_tests.log 2>&1
+grep -v amdgpu gpurun_out/t8_tests.log | tail -6

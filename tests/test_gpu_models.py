@@ -284,6 +284,51 @@ def test_bert_tiny_golden(golden_bert_tiny):
     assert abs(float(cam.double().sum()) - 1.0) < 1e-4
 
 
+def test_bert_soft_mask_fused_equals_stock_and_oracle():
+    """with the producer kernels the mask Add's first operand must be the scaled scores WITHOUT the mask
+    (BERT.py:339-342).  A 0 / -10000 mask hides a doubled mask (R is exactly 0 at masked keys); a SOFT additive mask (-3.0 on
+    some keys, attention_mask = 0.9997) does not: the fused path must give the stock path's map, and both the oracle's on a
+    cache whose add.X[0] is recomputed from q k^T (oracle/model_cache.py)."""
+    from transformer_explainability_amd import bert, ops
+    from transformer_explainability_amd.generators import Generator
+    cfg = bert.BertConfigLite(vocab_size=100, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                              intermediate_size=256, max_position_embeddings=40, num_labels=2)
+    torch.manual_seed(11)
+    model = bert.BertForSequenceClassification(cfg).eval()
+    with torch.no_grad():
+        for _, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    model.to(dev())
+    B, N = 3, 24
+    ids = torch.randint(1, 100, (B, N), generator=torch.Generator().manual_seed(12)).to(dev())
+    mask = torch.ones(B, N)
+    mask[:, 5:9] = 0.9997            # extended mask (1 - m) * -10000 = -3.0: soft
+    mask[1, 20:] = 0.0               # and ordinary padding on one sample
+    mask = mask.to(dev())
+    gen = Generator(model)
+    assert not ops.USE_FUSED_PRODUCERS
+    outs = {}
+    for fused in (False, True):
+        ops.USE_FUSED_PRODUCERS = fused
+        try:
+            out = gen.generate_LRP(input_ids=ids, attention_mask=mask, start_layer=0).clone()
+            sa = model.bert.encoder.layer[0].attention.self
+            assert (sa._fused_anchor is not None) == fused, "the producer kernels must (not) have run"
+            ext = sa.add.X[1]
+            assert abs(float(ext[0, 0, 0, 5]) + 3.0) < 1e-2, float(ext[0, 0, 0, 5])
+            cache = bert_cache_from_model(model)
+            # the module's own cache of the Add operand is the UNMASKED scaled score tensor
+            check(f"bert_soft_mask.add_x0.fused={fused}", sa.add.X[0], cache["layers"][0]["mask_add_x0"], 1e-6)
+            oh = _one_hot_of(model.classifier.Y.detach().float().cpu())
+            ref = O.bert_relprop(oh, cache, num_heads=2, start_layer=0)
+            _assert_map(f"bert_soft_mask.oracle.fused={fused}", out, ref["map"], norm_tol=2e-4, rel_tol=3e-4)
+            outs[fused] = out
+        finally:
+            ops.USE_FUSED_PRODUCERS = False
+    _assert_map("bert_soft_mask.fused_vs_stock", outs[True], outs[False], norm_tol=2e-4, rel_tol=3e-4)
+
+
 def test_bert_base_pruned_default_start_layer(golden_bert_base, golden_bands):
     """Generator(prune=True) at the reference's default start_layer = 11: only the last layer's rules run; same vector."""
     from transformer_explainability_amd import bert

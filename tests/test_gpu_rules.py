@@ -273,6 +273,58 @@ def test_linear_x6_schedules_are_bitwise_equal(T, in_f, out_f):
         ops.USE_LINEAR_X6, ops.X6_CHECK, ops.X6_TILE, ops.X6_FLAGS = was, False, 0, 0
 
 
+@pytest.mark.parametrize("variant,alpha", [("lrp", 1.0), ("lrp", 2.0), ("ours", 2.0), ("ours", 1.5)])
+@pytest.mark.parametrize("T,in_f,out_f", [(394, 768, 2304), (300, 3072, 768), (257, 128, 256), (600, 1024, 1024)])
+def test_linear_x6_variant_lrp_and_alpha(variant, alpha, T, in_f, out_f):
+    """variant lrp (modules/layers_lrp.py:188-211: S1 = sd(R, X+ W+^T), S2 = sd(R, X- W-^T)) and the
+    inhibitor half alpha * f(pw, nw, px, nx) - beta * f(nw, pw, px, nx) (layers_ours.py:225-228) on the x6 kernels
+    (te_linear_relprop_x6_general_f32): against the oracle, against the fp32-MFMA kernels of te_linear.hip, no less accurate
+    against fp64 than those, and bitwise independent of tile geometry, stream-K cuts and batch composition."""
+    from transformer_explainability_amd import ops
+    X, W, R = rnd((T, in_f), 141), rnd((out_f, in_f), 142, 0.05), rnd((T, out_f), 143, 0.01)
+    bias = rnd((out_f,), 144, 0.3)
+    X[1] = 0.0
+    X[2] = X[2].abs() + 0.01
+    W[:5] = -W[:5].abs() - 0.001                                 # row 2 against these: every product negative
+    Xd, Wd, bd, Rd = X.to(dev()), W.to(dev()), bias.to(dev()), R.to(dev())
+    Y = torch.nn.functional.linear(Xd, Wd, bd)
+    was = ops.USE_LINEAR_X6
+    try:
+        ops.USE_LINEAR_X6 = False
+        fp32 = ops.linear_relprop(Rd, Xd, Wd, alpha=alpha, variant=variant, Y=Y, bias=bd)
+        ops.USE_LINEAR_X6, ops.X6_CHECK = True, True
+        assert bool(ops._lib.load().te_linear_relprop_x6_general_supported(T, in_f, out_f, 1 if variant == "lrp" else 0))
+        cache = {}
+        ops.x6_raise_if_failed()
+        got = ops.linear_relprop(Rd, Xd, Wd, alpha=alpha, variant=variant, Y=Y, bias=bd, cache=cache)
+        assert ("x6_planes_lrp" if variant == "lrp" else "x6_planes") in cache, "the x6 kernels must have run"
+        ref = O.linear_relprop(R, X, W, alpha, variant)
+        tag = f"({variant},{alpha},{T},{in_f},{out_f})"
+        assert torch.isfinite(got).all()
+        check("linear_x6_general" + tag, got, ref, 4e-5)
+        check("linear_x6_general_vs_fp32_mfma" + tag, got, fp32, 4e-5)
+        ref64 = O.linear_relprop(R.double(), X.double(), W.double(), alpha, variant)
+        d6, d32 = got.cpu().double() - ref64, fp32.cpu().double() - ref64
+        r6, r32 = float(d6.pow(2).mean().sqrt()), float(d32.pow(2).mean().sqrt())
+        record("linear_x6_general_fp64" + tag, x6_rms=r6, fp32_mfma_rms=r32, x6_max=float(d6.abs().max()),
+               fp32_mfma_max=float(d32.abs().max()))
+        assert r6 <= 1.25 * r32 + 1e-10 * float(ref64.abs().max()), (r6, r32)
+        # geometry / schedule / batch composition: the same bits
+        for tile in (1, 2, 3):
+            for grid in (0, ops.TE_X6_TEST_SMALL_GRID):
+                ops.X6_TILE, ops.X6_FLAGS = tile, grid
+                assert torch.equal(ops.linear_relprop(Rd, Xd, Wd, alpha=alpha, variant=variant, Y=Y, bias=bd, cache=cache),
+                                   got), (tile, grid)
+        ops.X6_TILE, ops.X6_FLAGS = 0, 0
+        h = T // 2
+        half = ops.linear_relprop(Rd[:h].contiguous(), Xd[:h].contiguous(), Wd, alpha=alpha, variant=variant,
+                                  Y=Y[:h].contiguous(), bias=bd, cache=cache)
+        assert torch.equal(half, got[:h])
+        ops.x6_raise_if_failed()
+    finally:
+        ops.USE_LINEAR_X6, ops.X6_CHECK, ops.X6_TILE, ops.X6_FLAGS = was, False, 0, 0
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3], ids=["128x256", "256x256", "128x128"])
 def test_linear_x6_lost_handover_is_loud(tile):
     """VERDICT r3 item 2 / ADVICE r3: a stream-K hand-over that never arrives must not yield a plausible result.  The test

@@ -362,3 +362,46 @@ def test_index_select_host_copy_follows_in_place_edits():
     idx.fill_(3)
     y = m(x, 1, idx)
     assert m._index_host == 3 and torch.equal(y, x[:, 3:4])
+
+
+def test_x6_plane_cache_is_scratch_not_state():
+    """the bf16 operand planes a Linear layer caches (rules.x6_cache) outlive a forward pass.  They are keyed on
+    the weight as the caller holds it (address, strides, version counter): an in-place edit autograd records changes the
+    key; one it cannot see (``.data``) needs ops.x6_invalidate; load_state_dict and .to() / .float() drop them; they are
+    never pickled or deep-copied (torch.save(model) must not serialise device scratch)."""
+    import copy
+    import pickle
+    from transformer_explainability_amd import ops, rules
+    lin = rules.Linear(8, 4)
+    k0 = ops._weight_key(lin.weight.detach())
+    assert ops._weight_key(lin.weight.detach()) == k0                       # detach() shares storage AND version counter
+    with torch.no_grad():
+        lin.weight.mul_(2.0)
+    k1 = ops._weight_key(lin.weight.detach())
+    assert k1 != k0                                                         # recorded in-place edit -> new key
+    lin.weight.data.mul_(0.5)                                               # NOT recorded: same key (documented) ...
+    assert ops._weight_key(lin.weight.detach()) == k1
+    rules.x6_cache(lin)["x6_planes"] = (k1, torch.zeros(3))
+    assert ops.x6_invalidate(lin) == 1 and not rules.x6_cache(lin)          # ... hence the explicit invalidation
+    # a non-contiguous weight is keyed as the caller holds it (its contiguous copy would have version 0 and a recycled address)
+    wt = torch.randn(8, 4).t()
+    assert ops._weight_key(wt) != ops._weight_key(wt.contiguous())
+    # whole-model invalidation, load_state_dict, dtype / device moves
+    model = torch.nn.Sequential(rules.Linear(8, 8), rules.Linear(8, 4))
+    for m in model:
+        rules.x6_cache(m)["x6_planes"] = ("k", torch.zeros(1))
+    assert ops.x6_invalidate(model) == 2
+    for m in model:
+        rules.x6_cache(m)["x6_planes"] = ("k", torch.zeros(1))
+    model.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    assert all(not rules.x6_cache(m) for m in model)
+    rules.x6_cache(model[0])["x6_planes"] = ("k", torch.zeros(1))
+    model.double()
+    assert not rules.x6_cache(model[0])
+    # pickling / deepcopy leave the scratch behind
+    rules.x6_cache(lin)["x6_planes"] = (k1, torch.zeros(1000))
+    lin2 = copy.deepcopy(lin)
+    assert "_te_cache" not in lin2.__dict__ and torch.equal(lin2.weight, lin.weight)
+    lin3 = pickle.loads(pickle.dumps(lin))
+    assert "_te_cache" not in lin3.__dict__
+    assert "x6_planes" in rules.x6_cache(lin)                               # the original keeps its planes

@@ -67,6 +67,12 @@ SIGNATURES = {
     "te_linear_relprop_x6_f32": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _P, _P, _SZ,
                                       _P]),
     "te_linear_relprop_x6_check": (_I, [_P, _I64, _I64, _I64, _P]),
+    "te_linear_relprop_x6_general_supported": (_I, [_I64, _I64, _I64, _I]),
+    "te_linear_x6_weight_planes_lrp_bytes": (_SZ, [_I64, _I64]),
+    "te_linear_x6_prepare_weights_lrp_f32": (_I, [_P, _I64, _I64, _P, _SZ, _P]),
+    "te_linear_relprop_x6_general_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
+    "te_linear_relprop_x6_general_f32": (_I, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _I,
+                                              _I, _P, _P, _SZ, _P]),
     "te_gemm_x6_supported": (_I, [_I64, _I64, _I64]),
     "te_gemm_x6_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_linear_x6_split_matrix_f32": (_I, [_P, _I64, _I64, _I, _P, _SZ, _P]),

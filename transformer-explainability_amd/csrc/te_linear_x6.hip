@@ -42,6 +42,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "te_common.h"
 
@@ -59,7 +60,12 @@ constexpr int kSpinMillis = 250;               // bounded wait for a predecessor
 constexpr int kErrWord = 1023;                 // flags[0 .. 767] = hand-over flags of a pass, flags[kErrWord] = its error word
 
 
-enum { MODE_Z = 0, MODE_C = 1, MODE_G = 2 };      // Z-pass, C-pass, plain GEMM out = B A^T + bias
+// Z-pass, C-pass, plain GEMM out = B A^T + bias; round 4, for variant lrp and alpha != 1 (layers_lrp.py:188-211,
+// layers_ours.py:225-228): MODE_ZI = the inhibitor's Z-pass of variant ours from the same product, Z' = ((Y - b) - |X||W|^T)/2
+// = X+ W-^T + X- W+^T; MODE_Z1 = a one-sided Z-pass, S = sd(R, acc) (acc = X+ W+^T ...: same-sign terms, no cancellation);
+// MODE_CI = the C-pass with the signs crossed, out += scale (X+ . (S W-) + X- . (S W+)); MODE_X = a product masked by one
+// sign of X, out (+)= scale (X+- . acc).
+enum { MODE_Z = 0, MODE_C = 1, MODE_G = 2, MODE_ZI = 3, MODE_Z1 = 4, MODE_CI = 5, MODE_X = 6 };
 
 #define TE_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
@@ -184,6 +190,17 @@ __device__ __forceinline__ float exact_z(const float* __restrict__ x, const floa
   return z1 + z2;
 }
 
+// the inhibitor's Z of variant ours, k-ordered: X+ W-^T + X- W+^T (layers_ours.py:226: f(nw, pw, px, nx))
+__device__ __forceinline__ float exact_zi(const float* __restrict__ x, const float* __restrict__ w, int64_t K) {
+  float z1 = 0.0f, z2 = 0.0f;
+  for (int64_t k = 0; k < K; ++k) {
+    const float xv = x[k], wv = w[k];
+    z1 = fmaf(fmaxf(xv, 0.0f), fminf(wv, 0.0f), z1);
+    z2 = fmaf(fminf(xv, 0.0f), fmaxf(wv, 0.0f), z2);
+  }
+  return z1 + z2;
+}
+
 struct X6Params {
   const unsigned char* A;      // weight-side planes: P3 of |W| (Z-pass) or P6 of W+^T / W-^T (C-pass)
   const unsigned char* B;      // activation-side planes (P3): |X| (Z-pass) or S (C-pass)
@@ -220,6 +237,9 @@ struct X6Params {
   int rps;
   // C-pass epilogue
   float* out;
+  float scale;                 // MODE_C / MODE_CI / MODE_X: factor on the result (alpha, -beta)
+  int accum;                   // MODE_X: 1 = add to what out holds (MODE_CI always does)
+  int x_sign;                  // MODE_X: +1 = X+ masks the product, -1 = X-
 };
 
 __device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* lds_wave_base) {
@@ -266,7 +286,9 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
   static_assert(NST == 2 || NST == 3, "two or three LDS stages");
   using GEO = X6Geo<WM>;
   constexpr int NW = GEO::NW, NWM = GEO::NWM, NWN = GEO::NWN, MI = GEO::MI;
-  constexpr int G = (MODE == MODE_C) ? 6 : 3;        // pieces of one A group (32 rows [x 2 signs]) per K16 step
+  constexpr bool IS_Z = (MODE == MODE_Z || MODE == MODE_ZI || MODE == MODE_Z1);
+  constexpr bool IS_C = (MODE == MODE_C || MODE == MODE_CI);
+  constexpr int G = IS_C ? 6 : 3;                    // pieces of one A group (32 rows [x 2 signs]) per K16 step
   constexpr int NPA = GEO::NPA, NPB = GEO::NPB;      // 1-KiB pieces of one stage: weight side, activation side
   constexpr int NP = NPA + NPB;
   static_assert(NPA / 3 == NW, "each wave stages one weight-side block");
@@ -337,7 +359,7 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
     // ---- what this wave stages per step: the three planes of ONE weight-side 32-row block [one sign] and of PBW
     //      activation-side blocks -- each 3 KiB contiguous in memory and in the stage; wave-uniform pointers ----
     const unsigned char* srcA;
-    if constexpr (MODE != MODE_C)
+    if constexpr (!IS_C)
       srcA = p.A + (int64_t)(tm * GROUPS + wave) * p.a_group_stride + (int64_t)(kseg0 + k0) * kRB;
     else
       srcA = p.A + (int64_t)(tm * GROUPS + (wave >> 1)) * p.a_group_stride + (int64_t)(kseg0 + k0) * (2 * kRB) + (wave & 1) * kRB;
@@ -641,7 +663,7 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
     // The loads of a block are issued as one batch BEFORE the previous block's stores (hipcc keeps loads behind stores
     // that may alias, and a store then costs a full round trip per `s_waitcnt vmcnt`): first light of this kernel spent
     // 110 us per tile in a load -> wait -> store -> wait chain.
-    if constexpr (MODE == MODE_Z) {
+    if constexpr (IS_Z) {
       const int nksS = p.out_f >> 4;
       int64_t tl[2];
       bool live[2], blk[2];
@@ -670,11 +692,12 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
         const int ni = bi / MI, mi = bi % MI;
         const int j0 = (tm * (NWM * MI) + wm * MI + mi) * 32;
         const float* Rrow = p.R + tl[ni] * p.out_f + j0 + 4 * h;
-        const float* Yrow = p.Y + tl[ni] * p.out_f + j0 + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          r4[buf][g] = *reinterpret_cast<const f32x4*>(Rrow + 8 * g);
-          y4[buf][g] = *reinterpret_cast<const f32x4*>(Yrow + 8 * g);
+        for (int g = 0; g < 4; ++g) r4[buf][g] = *reinterpret_cast<const f32x4*>(Rrow + 8 * g);
+        if constexpr (MODE != MODE_Z1) {
+          const float* Yrow = p.Y + tl[ni] * p.out_f + j0 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) y4[buf][g] = *reinterpret_cast<const f32x4*>(Yrow + 8 * g);
         }
       };
       if constexpr (NBUF == 2) load_block(0, 0);
@@ -697,8 +720,18 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const float a_abs = acc[mi][ni][4 * g + c];
-            const float z = 0.5f * ((y4[buf][g][c] - b4[c]) + a_abs);
-            const bool cancel = !(z > kCancelTol * a_abs);
+            float z;
+            bool cancel;
+            if constexpr (MODE == MODE_Z) {              // Z  = X+ W+^T + X- W-^T = ((Y - b) + |X||W|^T) / 2  (>= 0)
+              z = 0.5f * ((y4[buf][g][c] - b4[c]) + a_abs);
+              cancel = !(z > kCancelTol * a_abs);
+            } else if constexpr (MODE == MODE_ZI) {      // Z' = X+ W-^T + X- W+^T = ((Y - b) - |X||W|^T) / 2  (<= 0)
+              z = 0.5f * ((y4[buf][g][c] - b4[c]) - a_abs);
+              cancel = !(-z > kCancelTol * a_abs);
+            } else {                                     // one-sided product: the accumulator is Z
+              z = a_abs;
+              cancel = false;
+            }
             bad |= (cancel ? 1u : 0u) << (4 * g + c);
             float rr = r4[buf][g][c];
             if (p.rs) rr = rr * f[ni];
@@ -744,7 +777,8 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
             for (int e = 0; e < 16; ++e) {
               if ((bad >> e) & 1u) {
                 const int jj = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
-                const float z = exact_z(p.X + tl[ni] * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f);
+                const float z = (MODE == MODE_ZI) ? exact_zi(p.X + tl[ni] * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f)
+                                                  : exact_z(p.X + tl[ni] * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f);
                 float rr = Rrow[jj];
                 if (p.rs) rr = rr * f[ni];
                 unsigned pl[3];
@@ -781,6 +815,33 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
             if (t < p.T) *reinterpret_cast<f32x4*>(orow + mi * 32 + 8 * g) = o;
           }
       }
+    } else if constexpr (MODE == MODE_X) {
+      // masked product (variant lrp's C-pass, one sign at a time: layers_lrp.py:201-202): out[t][m] (+)= scale * (X+-[t][m] * acc)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int64_t t = ((int64_t)tn * (GEO::TT / 32) + wn * 2 + ni) * 32 + tc;
+        const int64_t off = (t < p.T ? t : 0) * p.out_f + (tm * (NWM * MI) + wm * MI) * 32 + 4 * h;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 xv[4], pv[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            xv[g] = *reinterpret_cast<const f32x4*>(p.X + off + mi * 32 + 8 * g);
+            pv[g] = p.accum ? *reinterpret_cast<const f32x4*>(p.out + off + mi * 32 + 8 * g) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float xm = (p.x_sign > 0) ? fmaxf(xv[g][c], 0.0f) : fminf(xv[g][c], 0.0f);
+              const float v = p.scale * (xm * acc[mi][ni][4 * g + c]);
+              o[c] = p.accum ? pv[g][c] + v : v;
+            }
+            if (t < p.T) *reinterpret_cast<f32x4*>(p.out + off + mi * 32 + 8 * g) = o;
+          }
+        }
+      }
     } else {
       f32x4 x4[2][MI / 2][4];
       int64_t tt[2];
@@ -809,7 +870,15 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
             for (int c = 0; c < 4; ++c) {
               const float xv = x4[ni][il][g][c];
               const float xp = fmaxf(xv, 0.0f), xn = fminf(xv, 0.0f);
-              o[c] = 1.0f * (xp * acc[2 * il][ni][4 * g + c] + xn * acc[2 * il + 1][ni][4 * g + c]);
+              if constexpr (MODE == MODE_C)     // alpha * (X+ . (S W+) + X- . (S W-))                  layers_ours.py:222-228
+                o[c] = p.scale * (xp * acc[2 * il][ni][4 * g + c] + xn * acc[2 * il + 1][ni][4 * g + c]);
+              else                              // out - beta * (X+ . (S' W-) + X- . (S' W+)): scale = -beta
+                o[c] = p.scale * (xp * acc[2 * il + 1][ni][4 * g + c] + xn * acc[2 * il][ni][4 * g + c]);
+            }
+            if constexpr (MODE == MODE_CI) {
+              const f32x4 prev = *reinterpret_cast<const f32x4*>(orow + 8 * g);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] = prev[c] + o[c];
             }
             if (live[ni]) *reinterpret_cast<f32x4*>(orow + 8 * g) = o;
           }
@@ -911,7 +980,7 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
 // traffic in flight costs more than its latency cover buys.
 template <int MODE>
 int launch_x6_mode(int wm, bool three_stages, const X6Params& p, hipStream_t stream) {
-  if constexpr (MODE != MODE_C) {
+  if constexpr (MODE != MODE_C && MODE != MODE_CI) {
     if (p.seg_part && p.seg_flags && kseg_rule((int64_t)p.nks * 16, p.rows_w) == 2) {
       if (wm == 2) return launch_x6<2, MODE, 0, 2, 2>(p, stream);
       if (wm == 1) return launch_x6<1, MODE, 0, 2, 2>(p, stream);
@@ -1181,6 +1250,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   p.rs_stride = r_scale_stride;
   p.rps = (int)(r_scale ? rows_per_sample : 1);
   p.out = out;
+  p.scale = 1.0f;
   p.status = status;
   p.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
   p.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
@@ -1236,6 +1306,209 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
 #endif
     rc = launch_x6_mode<MODE_C>(wm, three_stages, p, stream);
     if (rc != TE_OK) return rc;
+  }
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// The rule for EVERY variant and alpha on the same kernels: modules/layers_lrp.py:188-211 (variant lrp:
+// S1 = sd(R, X+ W+^T), S2 = sd(R, X- W-^T) -- separate denominators) and the inhibitor half of both variants
+// (layers_ours.py:225-228: R = alpha * f(pw, nw, px, nx) - beta * f(nw, pw, px, nx), beta = alpha - 1).
+//   ours: Z-pass (S) -> C-pass scaled by alpha -> [beta != 0] MODE_ZI (S' from the SAME |X||W|^T product, Z' = ((Y - b) - A)/2)
+//         -> MODE_CI: out += -beta (X+ . (S' W-) + X- . (S' W+))                                   18 (+18) bf16 product units
+//   lrp : four one-sided launches per half: MODE_Z1 on (W+, X+) -> S1, on (W-, X-) -> S2; MODE_X on (W+^T, S1) masked by X+,
+//         on (W-^T, S2) masked by X- (accumulating); the inhibitor half crosses the weight signs.   24 (+24) units
+// Every product is an x6 product (six bf16 partial products, fp32 accumulation), every output one k-ordered chain (two where
+// kseg_rule splits K): bitwise batch-invariant like the default rule.
+extern "C" int te_linear_relprop_x6_general_supported(int64_t T, int64_t in_f, int64_t out_f, int variant) {
+  if (!te_linear_relprop_x6_supported(T, in_f, out_f)) return 0;
+  if (variant == TE_VARIANT_LRP) return (in_f % 128 == 0) ? 1 : 0;       // the masked products have in_f weight-side rows
+  return variant == TE_VARIANT_OURS ? 1 : 0;
+}
+
+extern "C" size_t te_linear_x6_weight_planes_lrp_bytes(int64_t in_f, int64_t out_f) {
+  if (!te_linear_relprop_x6_general_supported(1, in_f, out_f, TE_VARIANT_LRP)) return 0;
+  // P3 of W+ and W- (rows = out_f, K = in_f), then P3 of W+^T and W-^T (rows = in_f, K = out_f)
+  return 2 * te_align_up(planes_bytes(out_f, in_f), 256) + 2 * te_align_up(planes_bytes(in_f, out_f), 256);
+}
+
+extern "C" int te_linear_x6_prepare_weights_lrp_f32(const float* W, int64_t in_f, int64_t out_f, void* planes,
+                                                    size_t planes_bytes_, te_stream_t stream_) {
+  if (!W || !planes) return TE_ERR_INVALID_ARG;
+  if (!te_linear_relprop_x6_general_supported(1, in_f, out_f, TE_VARIANT_LRP) || !te_aligned16(W)) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes_ < te_linear_x6_weight_planes_lrp_bytes(in_f, out_f) || !te_aligned16(planes)) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned char* q = (unsigned char*)planes;
+  const size_t za = te_align_up(planes_bytes(out_f, in_f), 256), ca = te_align_up(planes_bytes(in_f, out_f), 256);
+  const dim3 gz((unsigned)(out_f / 32), (unsigned)te_ceil_div(in_f / 16, 8)), gc((unsigned)(in_f / 32), (unsigned)te_ceil_div(out_f / 16, 8));
+  split_kernel<OP_POS, false><<<gz, dim3(256), 0, stream>>>(W, q, out_f, in_f, 3, 0);
+  split_kernel<OP_NEG, false><<<gz, dim3(256), 0, stream>>>(W, q + za, out_f, in_f, 3, 0);
+  split_kernel<OP_POS, true><<<gc, dim3(256), 0, stream>>>(W, q + 2 * za, in_f, out_f, 3, 0);
+  split_kernel<OP_NEG, true><<<gc, dim3(256), 0, stream>>>(W, q + 2 * za + ca, in_f, out_f, 3, 0);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+constexpr int kGeneralPasses = 8;
+
+extern "C" size_t te_linear_relprop_x6_general_workspace_bytes(int64_t T, int64_t in_f, int64_t out_f, int variant) {
+  if (!te_linear_relprop_x6_general_supported(T, in_f, out_f, variant)) return 0;
+  // two plane sets of the input side (|X|, or X+ and X-), two of the output side (S / S', or S1 and S2)
+  return 2 * te_align_up(planes_bytes(T, in_f), 256) + 2 * te_align_up(planes_bytes(T, out_f), 256) + kPartialBytes +
+         kGeneralPasses * kFlagBytes + std::max(seg_region_bytes(T, in_f, out_f), seg_region_bytes(T, out_f, in_f));
+}
+
+extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_scale, int64_t r_scale_stride,
+                                                int64_t rows_per_sample, const float* X, const float* W,
+                                                const void* w_planes, const void* w_planes_lrp, const void* x_abs_planes,
+                                                const float* Y, const float* bias, float* out, int64_t T, int64_t in_f,
+                                                int64_t out_f, float alpha, int variant, int flags, unsigned* status,
+                                                void* ws, size_t ws_bytes, te_stream_t stream_) {
+  if (!R || !X || !W || !out || T <= 0) return TE_ERR_INVALID_ARG;
+  if (!te_linear_relprop_x6_general_supported(T, in_f, out_f, variant)) return TE_ERR_UNSUPPORTED;
+  const bool lrp = variant == TE_VARIANT_LRP;
+  if (lrp ? !w_planes_lrp : (!w_planes || !Y)) return TE_ERR_INVALID_ARG;
+  if (!ws || ws_bytes < te_linear_relprop_x6_general_workspace_bytes(T, in_f, out_f, variant) || !te_aligned16(ws))
+    return TE_ERR_WORKSPACE;
+  if (!te_aligned16(X) || !te_aligned16(W) || !te_aligned16(R) || (Y && !te_aligned16(Y)) || !te_aligned16(out) ||
+      (w_planes && !te_aligned16(w_planes)) || (w_planes_lrp && !te_aligned16(w_planes_lrp)) ||
+      (bias && !te_aligned16(bias)) || (x_abs_planes && !te_aligned16(x_abs_planes)))
+    return TE_ERR_UNSUPPORTED;
+  if (r_scale && (rows_per_sample <= 0 || rows_per_sample > 0x7fffffff || T % rows_per_sample)) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const float beta = alpha - 1.0f;
+  unsigned char* q = (unsigned char*)ws;
+  unsigned char* Xa = q;                                   // |X|   or X+
+  q += te_align_up(planes_bytes(T, in_f), 256);
+  unsigned char* Xb = q;                                   //        or X-
+  q += te_align_up(planes_bytes(T, in_f), 256);
+  unsigned char* Sa = q;                                   // S / S' or S1
+  q += te_align_up(planes_bytes(T, out_f), 256);
+  unsigned char* Sb = q;                                   //        or S2
+  q += te_align_up(planes_bytes(T, out_f), 256);
+  float* partial = (float*)q;
+  q += kPartialBytes;
+  unsigned* flag_words = (unsigned*)q;
+  q += kGeneralPasses * kFlagBytes;
+  unsigned char* const seg_region = q;
+  zero_words_kernel<<<dim3(kGeneralPasses * kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
+
+  X6Params base{};
+  base.T = T;
+  base.ncb = (int)te_ceil_div(T, 32);
+  base.partial = partial;
+  base.R = R;
+  base.Y = Y;
+  base.bias = bias;
+  base.X = X;
+  base.W = W;
+  base.rs = r_scale;
+  base.rs_stride = r_scale_stride;
+  base.rps = (int)(r_scale ? rows_per_sample : 1);
+  base.out = out;
+  base.status = status;
+  base.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
+  base.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
+  const bool three_stages = (flags & TE_X6_STAGES_3) != 0;
+  const int pin = flags & 3;
+  int pass = 0;
+  // one launch: a Z-like pass (K = in_f, weight-side rows = out_f) or an output-side pass (K = out_f)
+  auto seg_setup = [&](X6Params& p, int64_t K, int64_t rows_w) {
+    p.seg_part = nullptr, p.seg_flags = nullptr;
+    if (kseg_rule(K, rows_w) == 2) {
+      p.seg_part = (float*)seg_region;
+      p.seg_flags = (unsigned*)(seg_region + seg_part_bytes(T, K, rows_w));
+      zero_words_kernel<<<dim3((unsigned)(seg_flag_words(T, K, rows_w) / 1024)), dim3(256), 0, stream>>>(
+          reinterpret_cast<u32x4*>(p.seg_flags));
+    }
+  };
+  auto z_like = [&](auto mode_tag, const unsigned char* A, const unsigned char* B, unsigned char* S) -> int {
+    constexpr int MODE = decltype(mode_tag)::value;
+    X6Params p = base;
+    p.in_f = (int)in_f, p.out_f = (int)out_f;
+    p.A = A, p.B = B, p.S = S;
+    p.nks = (int)(in_f / 16);
+    p.a_group_stride = (int64_t)p.nks * kRB;
+    p.b_rb_stride = (int64_t)p.nks * kRB;
+    p.rows_w = (int)out_f;
+    p.flags = flag_words + (size_t)(pass++) * (kFlagBytes / 4);
+    seg_setup(p, in_f, out_f);
+    const int wm = choose_geo(pick_wm(in_f, out_f), T, out_f, pin, 256, true, kseg_rule(in_f, out_f));
+    return launch_x6_mode<MODE>(wm, three_stages, p, stream);
+  };
+  int rc;
+  if (!lrp) {
+    const unsigned char* wz = (const unsigned char*)w_planes;
+    const unsigned char* wc = wz + te_align_up(planes_bytes(out_f, in_f), 256);
+    if (!x_abs_planes) {
+      rc = te_linear_x6_split_abs_f32(X, T, in_f, Xa, planes_bytes(T, in_f), stream_);
+      if (rc != TE_OK) return rc;
+      x_abs_planes = Xa;
+    }
+    auto c_like = [&](auto mode_tag, float scale) -> int {
+      constexpr int MODE = decltype(mode_tag)::value;
+      X6Params p = base;
+      p.in_f = (int)in_f, p.out_f = (int)out_f;
+      p.A = wc, p.B = Sa;
+      p.nks = (int)(out_f / 16);
+      p.a_group_stride = (int64_t)p.nks * 2 * kRB;
+      p.b_rb_stride = (int64_t)p.nks * kRB;
+      p.rows_w = (int)(2 * in_f);
+      p.scale = scale;
+      p.flags = flag_words + (size_t)(pass++) * (kFlagBytes / 4);
+      return launch_x6_mode<MODE>(choose_geo(pick_wm(in_f, out_f), T, 2 * in_f, pin), three_stages, p, stream);
+    };
+    rc = z_like(std::integral_constant<int, MODE_Z>{}, wz, (const unsigned char*)x_abs_planes, Sa);
+    if (rc != TE_OK) return rc;
+    rc = c_like(std::integral_constant<int, MODE_C>{}, alpha);
+    if (rc != TE_OK) return rc;
+    if (beta != 0.0f) {
+      rc = z_like(std::integral_constant<int, MODE_ZI>{}, wz, (const unsigned char*)x_abs_planes, Sa);      // S' over S
+      if (rc != TE_OK) return rc;
+      rc = c_like(std::integral_constant<int, MODE_CI>{}, -beta);
+      if (rc != TE_OK) return rc;
+    }
+  } else {
+    const size_t za = te_align_up(planes_bytes(out_f, in_f), 256), ca = te_align_up(planes_bytes(in_f, out_f), 256);
+    const unsigned char* wq = (const unsigned char*)w_planes_lrp;
+    const unsigned char* Wp = wq, *Wn = wq + za, *WpT = wq + 2 * za, *WnT = wq + 2 * za + ca;
+    const dim3 gx((unsigned)te_ceil_div(T, 32), (unsigned)te_ceil_div(in_f / 16, 8));
+    split_kernel<OP_POS, false><<<gx, dim3(256), 0, stream>>>(X, Xa, T, in_f, 3, 0);
+    split_kernel<OP_NEG, false><<<gx, dim3(256), 0, stream>>>(X, Xb, T, in_f, 3, 0);
+    // out (+)= scale * (X^sign . (S W^t)):  product [T, out_f] x [out_f, in_f], weight-side rows = in_f
+    auto x_like = [&](const unsigned char* AT, const unsigned char* S, int sign, float scale, int accum) -> int {
+      X6Params p = base;
+      p.in_f = (int)out_f, p.out_f = (int)in_f;           // (plain-product naming: K, M)
+      p.A = AT, p.B = S;
+      p.nks = (int)(out_f / 16);
+      p.a_group_stride = (int64_t)p.nks * kRB;
+      p.b_rb_stride = (int64_t)p.nks * kRB;
+      p.rows_w = (int)in_f;
+      p.scale = scale, p.accum = accum, p.x_sign = sign;
+      p.flags = flag_words + (size_t)(pass++ % kGeneralPasses) * (kFlagBytes / 4);
+      seg_setup(p, out_f, in_f);
+      const int wm = choose_geo((in_f % 256 == 0) ? 2 : 1, T, in_f, pin, 192, true, kseg_rule(out_f, in_f));
+      return launch_x6_mode<MODE_X>(wm, three_stages, p, stream);
+    };
+    for (int half = 0; half < (beta != 0.0f ? 2 : 1); ++half) {
+      // half 0: f(pw, nw, px, nx) (activator); half 1: f(nw, pw, px, nx) (inhibitor) -- the weight signs cross
+      const unsigned char* w1 = half ? Wn : Wp, *w2 = half ? Wp : Wn, *w1T = half ? WnT : WpT, *w2T = half ? WpT : WnT;
+      const float sc = half ? -beta : alpha;
+      if (half) {       // the second half reuses the flag regions of the first: reset them (stream-ordered after their use)
+        pass = 0;
+        zero_words_kernel<<<dim3(kGeneralPasses * kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
+      }
+      rc = z_like(std::integral_constant<int, MODE_Z1>{}, w1, Xa, Sa);
+      if (rc != TE_OK) return rc;
+      rc = z_like(std::integral_constant<int, MODE_Z1>{}, w2, Xb, Sb);
+      if (rc != TE_OK) return rc;
+      rc = x_like(w1T, Sa, +1, sc, half);
+      if (rc != TE_OK) return rc;
+      rc = x_like(w2T, Sb, -1, sc, 1);
+      if (rc != TE_OK) return rc;
+    }
   }
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;

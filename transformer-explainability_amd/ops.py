@@ -172,12 +172,34 @@ def x6_raise_if_failed(device=None, reset: bool = True):
                            "holding CUs.  Re-run the step; set TE_LINEAR_X6=0 to use the fp32-MFMA kernels instead")
 
 
+def _weight_key(W: Tensor):
+    """Identity of a weight AS THE CALLER HOLDS IT (never of a contiguous copy, whose fresh version counter and recycled
+    address could collide): storage address, strides, shape, device and autograd's version counter.  What the counter
+    cannot see -- writes through ``.data`` (``p.data.copy_(ckpt)``, ``p.data.normal_()``, pruning masks) -- needs
+    ``x6_invalidate``; rules.Linear also drops its planes on ``load_state_dict`` and on ``.to()`` / ``.float()``."""
+    return (W.data_ptr(), W._version, tuple(W.shape), tuple(W.stride()), str(W.device))
+
+
+def x6_invalidate(obj) -> int:
+    """Drop the cached bf16 operand planes of a layer, or of every layer of a model (returns how many caches were cleared).
+    The planes outlive a forward pass and are keyed on autograd's version counter: call this after editing weights in a
+    way autograd does not record (``param.data...``), and re-capture any HIP graph that baked the old planes in."""
+    mods = obj.modules() if hasattr(obj, "modules") else [obj]
+    n = 0
+    for m in mods:
+        c = getattr(m, "__dict__", {}).get("_te_cache")
+        if c:
+            c.clear()
+            n += 1
+    return n
+
+
 def x6_weight_planes(W: Tensor, cache: Optional[dict] = None) -> Tensor:
     """bf16 operand planes of a Linear weight for te_linear_relprop_x6_f32, built once per weight version.  `cache` is a
-    dict owned by the layer (rules.Linear keeps one); the entry is keyed on storage address, shape and the tensor's
-    version counter, so an optimiser step or an in-place edit of the weight rebuilds the planes."""
+    dict owned by the layer (rules.Linear keeps one); the entry is keyed on the weight's identity (_weight_key), so an
+    optimiser step or an in-place edit of the weight rebuilds the planes."""
     out_f, in_f = W.shape
-    key = (W.data_ptr(), W._version, out_f, in_f, str(W.device))
+    key = _weight_key(W)
     if cache is not None:
         hit = cache.get("x6_planes")
         if hit is not None and hit[0] == key:
@@ -212,12 +234,31 @@ def gemm_x6_wanted(T: int, K: int, M: int) -> bool:
     return X6_GEMM == "all" or (K <= 1024 and M >= 2 * K)
 
 
+def x6_weight_planes_lrp(W: Tensor, cache: Optional[dict] = None) -> Tensor:
+    """P3 planes of max(W,0), min(W,0) and of their transposes: the weight side of te_linear_relprop_x6_general_f32 for
+    variant lrp (one-sided products); built once per weight version like x6_weight_planes."""
+    out_f, in_f = W.shape
+    key = _weight_key(W)
+    if cache is not None:
+        hit = cache.get("x6_planes_lrp")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    Wc = _c(W.detach())
+    with _on_device(Wc) as lib:
+        planes = _ws(lib.te_linear_x6_weight_planes_lrp_bytes(in_f, out_f), Wc)
+        _lib.check(lib.te_linear_x6_prepare_weights_lrp_f32(_ptr(Wc), in_f, out_f, _ptr(planes), planes.numel(),
+                                                            _stream(Wc)), "te_linear_x6_prepare_weights_lrp_f32")
+    if cache is not None:
+        cache["x6_planes_lrp"] = (key, planes)
+    return planes
+
+
 def x6_matrix_planes(W: Tensor, transposed: bool, cache: Optional[dict] = None) -> Tensor:
     """Signed bf16 operand planes of W [out, in] (transposed=False: rows = out, the forward product's weight side) or of
     W^T (transposed=True: rows = in, the input gradient's), built once per weight version (cache as x6_weight_planes)."""
     out_f, in_f = W.shape
     name = "x6_gemm_planes_T" if transposed else "x6_gemm_planes"
-    key = (W.data_ptr(), W._version, out_f, in_f, str(W.device))
+    key = _weight_key(W)
     if cache is not None:
         hit = cache.get(name)
         if hit is not None and hit[0] == key:
@@ -296,6 +337,44 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
     rs_ptr, rs_stride, rps = None, 0, 1
     if r_scale is not None:
         rs_ptr, rs_stride, rps = r_scale.data_ptr(), r_scale.stride(0), T // r_scale.shape[0]
+    # variant lrp and / or alpha != 1 on the x6 kernels (round 4; te_linear_relprop_x6_general_f32): one-sided products for
+    # lrp, the inhibitor half from the same |X||W|^T product for ours (which needs the cached forward output)
+    var_code = var & 0xff
+    general = (USE_LINEAR_X6 and not (var & TE_IMPL_SIMPLE) and not (var_code == TE_VARIANT_OURS and alpha == 1)
+               and all(t.data_ptr() % 16 == 0 for t in (Rc, Xc, Wc))
+               and (var_code == TE_VARIANT_LRP or (USE_FORWARD_OUTPUT and Y is not None))
+               and bool(_lib.load().te_linear_relprop_x6_general_supported(T, in_f, out_f, var_code)))
+    if general:
+        Yg = bg = None
+        if var_code == TE_VARIANT_OURS:
+            Yg = _c(Y.detach()).reshape(-1, out_f)
+            bg = None if bias is None else _c(bias.detach())
+            general = Yg.shape[0] == T and Yg.data_ptr() % 16 == 0 and (bg is None or bg.data_ptr() % 16 == 0)
+    if general:
+        rs_ptr, rs_stride, rps = None, 0, 1
+        if r_scale is not None:
+            rs_ptr, rs_stride, rps = r_scale.data_ptr(), r_scale.stride(0), T // r_scale.shape[0]
+        wp = x6_weight_planes(W, cache) if var_code == TE_VARIANT_OURS else None
+        wpl = x6_weight_planes_lrp(W, cache) if var_code == TE_VARIANT_LRP else None
+        xa = None
+        if cache is not None and var_code == TE_VARIANT_OURS:
+            hit = cache.pop("x_abs_planes", None)
+            if hit is not None and hit[0] == _x_abs_key(X, T, in_f):
+                xa = hit[1]
+        gemm = 2.0 * T * in_f * out_f
+        halves = 2 if alpha != 1 else 1
+        units = (18.0 if var_code == TE_VARIANT_OURS else 24.0) * halves
+        with _on_device(Xc) as lib, _timed("linear_x6_general", units * gemm,
+                                           halves * (6.0 * (2 * T * in_f + 3 * in_f * out_f + 2 * T * out_f) + 16.0 * T * in_f)):
+            ws = _ws(lib.te_linear_relprop_x6_general_workspace_bytes(T, in_f, out_f, var_code), Xc)
+            _lib.check(lib.te_linear_relprop_x6_general_f32(_ptr(Rc), rs_ptr, rs_stride, rps, _ptr(Xc), _ptr(Wc), _ptr(wp),
+                                                            _ptr(wpl), _ptr(xa), _ptr(Yg), _ptr(bg), _ptr(out), T, in_f,
+                                                            out_f, float(alpha), var_code, (X6_TILE | X6_FLAGS) & ~0x3c00,
+                                                            _ptr(x6_status(Xc.device)), _ptr(ws), ws.numel(), _stream(Xc)),
+                       "te_linear_relprop_x6_general_f32")
+            if X6_CHECK:
+                x6_raise_if_failed(Xc.device)
+        return out.reshape(*lead, in_f)
     if fwd:
         Yc = _c(Y.detach()).reshape(-1, out_f)
         bc = None if bias is None else _c(bias.detach())
@@ -303,10 +382,11 @@ def linear_relprop(R: Tensor, X: Tensor, W: Tensor, alpha: float = 1.0, variant=
             raise _lib.TeError(f"Linear.relprop: Y has {Yc.shape[0]} rows, X has {T}")
     if (fwd and USE_LINEAR_X6 and Yc.data_ptr() % 16 == 0 and (bc is None or bc.data_ptr() % 16 == 0)
             and _lib.load().te_linear_relprop_x6_supported(T, in_f, out_f)):
-        planes = x6_weight_planes(Wc, cache)
+        planes = x6_weight_planes(W, cache)           # (keyed on W as the caller holds it, not on a contiguous copy)
         xa = None       # the planes of |X| the layer's own forward product left behind (gemm_x6 keep_abs), if X is that tensor
         if cache is not None:
-            hit = cache.get("x_abs_planes")
+            # consumed once: 6 B per input element (0.4 GB per ViT-B block at batch 64) must not outlive the rule
+            hit = cache.pop("x_abs_planes", None)
             if hit is not None and hit[0] == _x_abs_key(X, T, in_f):
                 xa = hit[1]
         with _on_device(Xc) as lib:

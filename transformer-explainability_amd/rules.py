@@ -136,6 +136,21 @@ def x6_cache(module) -> dict:
 class Linear(nn.Linear, RelProp):
     """layers_ours.py:207-230 / layers_lrp.py:188-211 -> te_linear_relprop_f32."""
 
+    # The derived operand planes (x6_cache) are device scratch, not state: they are rebuilt on demand, so they are kept out of
+    # pickling / deepcopy / torch.save(model), and dropped whenever the parameters are replaced wholesale.
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_te_cache", None)
+        return state
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        ops.x6_invalidate(self)
+
+    def _apply(self, fn, *args, **kwargs):
+        ops.x6_invalidate(self)
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, x):
         from . import producers                      # 8f.1: forward and / or input gradient on te_gemm_x6_f32
         plan = producers.linear_plan(x, self)
