@@ -56,7 +56,13 @@ CONFIGS = {
     "vit_b16_224": (1, 64, "ViT-B/16 224^2"),
     "vit_l16_384": (2, 32, "ViT-L/16 384^2"),
     "bert_base_512": (3, 32, "BERT-base 512 tokens"),
+    # configs[4]: the ImageNet-seg style sweep, GLOBAL batch 256 sharded over the ranks (32 per GPU on 8), every image keyed by
+    # its global index, explained + up-sampled (SaliencySweep), ONE gather of all maps at the end.  --steps = global batches
+    # (default: the whole 50 000-image sweep = 196 steps); a 1-GPU run processes 256 per step itself.
+    "sweep50k": (4, 0, "ViT-B/16 224^2 sweep"),
 }
+SWEEP_GLOBAL_BATCH = 256
+SWEEP_IMAGES = 50_000
 
 
 def log(msg):
@@ -67,16 +73,21 @@ def log(msg):
 def _resolve(args):
     if args.overlap_backward == "auto":
         args.overlap_backward = "on"
+    if args.steps is None:
+        args.steps = -(-SWEEP_IMAGES // SWEEP_GLOBAL_BATCH) if args.config == "sweep50k" else 5
     return args
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 5; --config sweep50k: 196 = the whole 50 000-image sweep in global batches of 256)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="vit_b16_224",
-                    help="vit_b16_224 = BASELINE.json's headline (configs[1]); the others are configs[2] / configs[3]")
+                    help="vit_b16_224 = BASELINE.json's headline (configs[1]); vit_l16_384 / bert_base_512 = configs[2] / [3]; "
+                         "sweep50k = configs[4]: global batch 256 sharded over --gpus ranks, images keyed by global index, "
+                         "SaliencySweep (explain + x16 up-sampling), one gather of all maps after the last step")
     ap.add_argument("--batch", type=int, default=0, help="inputs per GPU per step (0 = the configuration's own)")
     ap.add_argument("--start-layer", type=int, default=None,
                     help="default: 1 for ViT (imagenet_seg_eval.py:196), 0 for BERT (every layer reaches the map)")
@@ -290,8 +301,14 @@ class Workload:
             self.B = args.batch
         B = self.B
         torch.manual_seed(0)
-        if args.config.startswith("vit"):
-            if args.config == "vit_b16_224":
+        self.sweep = args.config == "sweep50k"
+        if self.sweep:
+            world = int(os.environ.get("WORLD_SIZE", "1"))
+            if SWEEP_GLOBAL_BATCH % world:
+                sys.exit(f"--config sweep50k: the global batch of {SWEEP_GLOBAL_BATCH} does not divide over {world} ranks")
+            self.B = B = args.batch or SWEEP_GLOBAL_BATCH // world
+        if args.config.startswith("vit") or self.sweep:
+            if args.config in ("vit_b16_224", "sweep50k"):
                 model, side = vit.vit_base_patch16_224().eval(), 224
             else:
                 model, side = vit.vit_large_patch16_224(img_size=384).eval(), 384
@@ -301,10 +318,27 @@ class Workload:
                         p.add_(0.02 * torch.randn_like(p))
             self.cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
             self.start_layer = 1 if args.start_layer is None else args.start_layer
-            self.inputs = (torch.stack([synthetic_image(rank * B + i, (3, side, side)) for i in range(B)]).to(dev),)
+            if self.sweep:
+                # rank r owns the contiguous block [r K B, (r + 1) K B) of the K * world * B images (parallel.sweep_layout);
+                # step k explains its k-th batch.  All inputs resident in HBM before the timed region (600 KB per image).
+                from transformer_explainability_amd import parallel as par
+                K = args.steps + args.warmup
+                self.sweep_inputs = torch.empty((K, B, 3, side, side), dtype=torch.float32, device=dev)
+                lo = rank * args.steps * B
+                for k in range(K):                           # (warm-up batches recycle the first indices)
+                    for j in range(B):
+                        gi = lo + (k - args.warmup) % max(1, args.steps) * B + j
+                        self.sweep_inputs[k, j] = par.synthetic_image_on(gi, dev, (3, side, side))
+                self.inputs = (self.sweep_inputs[0],)
+                self.sweep_lo = lo
+            else:
+                self.inputs = (torch.stack([synthetic_image(rank * B + i, (3, side, side)) for i in range(B)]).to(dev),)
             self.model = model.to(dev)
             self.gen = LRP(self.model, overlap_backward=(args.overlap_backward == "on"),
                            prune=(args.prune == "on"))
+            if self.sweep:
+                from transformer_explainability_amd.sweep import SaliencySweep
+                self.saliency = SaliencySweep("transformer_attribution", lrp=self.gen, device=dev)
             self.tokens = (side // 16) ** 2 + 1
             self.out_cols = self.tokens - 1
             self.blocks = len(model.blocks)
@@ -329,6 +363,12 @@ class Workload:
             self.side = None
 
     def eager(self, *inputs):
+        if self.sweep:
+            # generate_visualizations.py:60-98: normalise, explain (method "grad" = transformer_attribution, start_layer 1),
+            # bilinear x16 + min-max; the [B,196] maps are what the final gather carries
+            heat, maps = self.saliency.explain(inputs[0], return_maps=True)
+            self.last_heat = heat
+            return maps
         if self.name.startswith("vit"):
             return self.gen.generate_LRP(inputs[0], method="transformer_attribution", start_layer=self.start_layer)
         return self.gen.generate_LRP(input_ids=inputs[0], attention_mask=inputs[1], start_layer=self.start_layer)
@@ -385,7 +425,7 @@ def cpu_baseline(args, wl):
     log(f"cpu_baseline: kind {kind} ({rh.reference_origin()}), {cores} usable cores (os.cpu_count() = {os.cpu_count()}), "
         f"{cpu_model_string()}")
     n_in = max(args.cpu_maps, 2) + 1
-    is_vit = wl.name.startswith("vit")
+    is_vit = wl.name.startswith("vit") or wl.sweep
     if is_vit:
         xs = torch.stack([synthetic_image(i, (3, wl.side, wl.side)) for i in range(n_in)])
     else:
@@ -396,7 +436,7 @@ def cpu_baseline(args, wl):
     if kind == "reference":
         if is_vit:
             mods = rh.load_reference_vit()
-            if wl.name == "vit_b16_224":
+            if wl.name in ("vit_b16_224", "sweep50k"):
                 model = mods["ViT_LRP"].vit_base_patch16_224(pretrained=False).eval()
             else:
                 model = mods["ViT_LRP"].vit_large_patch16_224(pretrained=False, img_size=384).eval()
@@ -421,7 +461,7 @@ def cpu_baseline(args, wl):
         from oracle.model_cache import bert_cache_from_model, vit_cache_from_model
         from transformer_explainability_amd import bert, vit
         if is_vit:
-            model = (vit.vit_base_patch16_224() if wl.name == "vit_b16_224"
+            model = (vit.vit_base_patch16_224() if wl.name in ("vit_b16_224", "sweep50k")
                      else vit.vit_large_patch16_224(img_size=384)).eval()
             model.load_state_dict(wl.cpu_state)
             heads = model.blocks[0].attn.num_heads
@@ -468,7 +508,7 @@ def cpu_baseline(args, wl):
     # the 1-thread figure for the headline configuration only: a ViT-L / BERT-512 map takes
     # minutes on one thread
     one = None
-    if wl.name == "vit_b16_224":
+    if wl.name in ("vit_b16_224", "sweep50k"):
         one = leg(1, 2) if cores > 1 else legs[cores]
     torch.set_num_threads(cores)
     return {"value": 1.0 / legs[best], "unit": wl.unit, "cores": best, "kind": kind,
@@ -506,6 +546,9 @@ def main():
     te._lib.require_device()
     dev = torch.device("cuda", int(os.environ.get("TE_DEVICE_OVERRIDE", local)))   # (override: one-GPU test rig)
     torch.cuda.set_device(dev)
+    cores = parallel.pin_rank_to_cores(local, world)      # N > 1: each rank enqueues from its own slice of the host cores
+    if cores:
+        log(f"rank {rank}: pinned to {cores} host cores (OMP_NUM_THREADS = {cores})")
     tuned = False
     if args.tuned_gemms == "on":
         tuned = te.enable_tuned_gemms()
@@ -538,7 +581,7 @@ def main():
     # their own and must never meet an open capture; replay afterwards is an ordinary launch.
     graphed = None
     lane_graphs = None           # --inflight N with graphs: one captured step (own static buffers) per lane
-    use_graph = args.graph == "on" or (args.graph == "auto" and args.config == "vit_b16_224")
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.config in ("vit_b16_224", "sweep50k"))
     if use_graph:
         try:
             if args.inflight == 1:
@@ -556,14 +599,24 @@ def main():
         assert (r, w) == (rank, world), (r, w, rank, world)
         log(f"rank {rank}: process group up ({torch.distributed.get_backend()})")
 
-    def step(eager=False):
+    sweep_maps = (torch.empty((args.steps, B, wl.out_cols), dtype=torch.float32, device=dev) if wl.sweep else None)
+
+    def step(eager=False, k=None):
+        inputs = wl.inputs if not wl.sweep else (wl.sweep_inputs[(args.warmup + k) if k is not None else 0],)
         if graphed is not None and not eager:
-            return graphed(*wl.inputs)
-        if eager:
+            out = graphed(*inputs)
+        elif eager:
             join()                       # the probe step runs alone: its kernel durations must be its own
-            return wl.eager_serial(*wl.inputs)
-        if lanes is None:
-            return wl.eager(*wl.inputs)
+            out = wl.eager_serial(*inputs)
+        elif lanes is None:
+            out = wl.eager(*inputs)
+        else:
+            out = None
+        if out is not None:
+            if wl.sweep and k is not None:
+                sweep_maps[k].copy_(out)         # (the graph's static output is overwritten by the next replay)
+            return out
+        inputs = wl.inputs
         # every tensor of a step is allocated, produced and consumed on that step's stream
         i = counter[0] % len(lanes)
         lane = lanes[i]
@@ -602,10 +655,13 @@ def main():
         # (eager configurations too: their other steps run as the library would -- relprop beside the backward pass, no events)
         probe = k == args.steps - 1
         timer.enabled = probe and not args.no_roofline
-        maps = step(eager=probe and not args.no_roofline)
+        maps = step(eager=probe and not args.no_roofline, k=k)
     host_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (GPU still running)
     join()
-    gathered = parallel.gather_maps(maps, world * B)
+    if wl.sweep:     # ONE collective for the whole sweep: every rank's [K * B, 196] block, in global order
+        gathered = parallel.gather_maps(sweep_maps.view(args.steps * B, wl.out_cols), world * args.steps * B)
+    else:
+        gathered = parallel.gather_maps(maps, world * B)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -620,14 +676,14 @@ def main():
             t = t.cpu()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert gathered.shape == (world * B, wl.out_cols) and torch.isfinite(gathered).all()
+    assert gathered.shape == (world * B * (args.steps if wl.sweep else 1), wl.out_cols) and torch.isfinite(gathered).all()
     ops.x6_raise_if_failed(dev)      # sticky device word of every x6 launch of the run (no synchronisation inside a step)
 
     # Rounds stay comparable: with the x6 Linear rules the same workload is timed once more on the fp32-MFMA kernels of
     # csrc/te_linear.hip (own graph capture, one warm-up, the same number of steps); N = 1 only, after the timed region.
     fp32_cmp = {}
     used_graph = graphed is not None or lane_graphs is not None
-    if args.linear == "x6" and world == 1:
+    if args.linear == "x6" and world == 1 and not wl.sweep:
         lane_graphs = None
         ops.USE_LINEAR_X6 = False
         ops.X6_GEMM = "off"          # the comparison run executes no bf16 MFMA at all: rules AND layer products on fp32 MFMAs
@@ -684,6 +740,10 @@ def main():
                                    f"{' (Linear rules: fp32 operands as three bf16 planes on bf16 MFMAs)' if args.linear == 'x6' else ''} (BASELINE.json "
                                    f"configs[{idx}], sharded by sample)",
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": wl.tokens, "blocks": wl.blocks,
+                       **({"sweep_images": world * B * args.steps, "sweep_note": "images keyed by GLOBAL index (rank r owns the "
+                           "contiguous block r of the sweep); each step = SaliencySweep.explain (generate_LRP + bilinear x16 + "
+                           "min-max, generate_visualizations.py:60-98) of one batch; ONE all_gather of all [n,196] maps after "
+                           "the last step, inside the timed region"} if wl.sweep else {}),
                        "start_layer": wl.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "steps_in_flight": args.inflight,
                        "relprop_beside_backward": args.overlap_backward == "on",

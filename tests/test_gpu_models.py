@@ -6,6 +6,8 @@ Tolerance (BASELINE.json north_star): heat-maps within 1e-4 fp32 of the referenc
 in magnitude, so the raw bar is met trivially; the tests therefore ALSO bound the relative L-inf error
 and the error after per-map min-max normalisation (what imagenet_seg_eval.py:217 consumes), whose
 fp32-reassociation noise band is 1e-5..1.3e-4 for the reference itself."""
+import os
+
 import pytest
 import torch
 
@@ -682,6 +684,48 @@ def test_vit_b16_linear_x6_path(vit_b16, golden_bands):
     model.to("cpu")
 
 
+@pytest.mark.parametrize("alpha", [1, 2])
+def test_vit_b16_orig_lrp_variant_on_x6(alpha):
+    """VERDICT r3 item 6 at model size: ViT-B/16 built over the lrp rule library (baselines/ViT/ViT_orig_LRP.py ->
+    modules/layers_lrp.py), method "grad" as ViT_orig_LRP calls it, alpha 1 and 2: every Linear rule runs on the x6 kernels
+    (te_linear_relprop_x6_general_f32), the map agrees with the oracle on the same cache to the literal 1e-4 (normalised)
+    bar and with the fp32-MFMA kernels far inside it, a batch equals its samples bitwise."""
+    from gpu_util import sliced_relprop_state
+    from transformer_explainability_amd import ops, rules_lrp, vit
+    ns = vit.make_vit_module(rules_lrp)
+    model = ns["vit_base_patch16_224"]().eval()
+    synthetic_init(model, 0)
+    model.to(dev())
+    B = 3
+    x = seeded_randn((B, 3, 224, 224), 5).to(dev())
+    out = model(x)
+    oh = _one_hot_of(out.detach())
+    from transformer_explainability_amd.generators import _attention_gradients
+    _attention_gradients((oh * out).sum(), [blk.attn for blk in model.blocks])
+    was = ops.USE_LINEAR_X6
+    try:
+        ops.USE_LINEAR_X6 = False
+        fp32_map = model.relprop(oh, method="grad", start_layer=1, alpha=alpha).clone()
+        ops.USE_LINEAR_X6, ops.X6_CHECK = True, True
+        x6_map = model.relprop(oh, method="grad", start_layer=1, alpha=alpha).clone()
+        assert "x6_planes_lrp" in model.blocks[3].mlp.fc1.__dict__.get("_te_cache", {}), "the x6 kernels must have run"
+        s = map_stats(x6_map, fp32_map)
+        record(f"vit_b16.orig_lrp.alpha{alpha}.x6_vs_fp32_mfma", **s)
+        assert s["normalised_max_abs"] <= 2e-5, s
+        cache = vit_cache_from_model(model)
+        ref = O.vit_relprop(oh.float().cpu(), cache, num_heads=12, start_layer=1, alpha=float(alpha), variant="lrp")
+        _assert_map(f"vit_b16.orig_lrp.alpha{alpha}.oracle_same_cache", x6_map, ref["map"], norm_tol=1e-4, rel_tol=3e-4)
+        for i in range(B):
+            with sliced_relprop_state(model, i, B):
+                one = model.relprop(oh[i:i + 1], method="grad", start_layer=1, alpha=alpha)
+                assert torch.equal(one, x6_map[i:i + 1]), i
+        ops.x6_raise_if_failed()
+    finally:
+        ops.USE_LINEAR_X6, ops.X6_CHECK = was, False
+    model.to("cpu")
+    torch.cuda.empty_cache()
+
+
 def test_bert_base_with_layer_producers(golden_bert_base, golden_bands):
     """BERT-base with its LayerNorm / GELU layers on the producer kernels (csrc/te_norm_act.hip; the attention blocks
     stay stock at this sequence length): logits agree with the stock forward to fp32 rounding, the HIP relprop agrees
@@ -756,13 +800,22 @@ def test_config1_vit_b16_batch64(vit_b16, golden_bands):
         ops.X6_CHECK = False
         assert maps.shape == (B, 196) and torch.isfinite(maps).all()
         oh = _one_hot_of(model.head.Y.detach())
-        for i in (0, 31, 63):
+        # the oracle on the cache of EVERY 4TH sample plus the ones in the partial tile (row 12 608 =
+        # 49 tiles of 256 + 64 rows: samples 63 and 62 end there) and the golden-band ones -- 19 of 64 -- each held to the
+        # LITERAL north-star bar: min-max-normalised |delta| <= 1e-4 at start_layer = 1 (measured 2e-7 ... 3e-6)
+        picked = sorted(set(range(0, B, 4)) | {31, 62, 63})
+        worst = 0.0
+        for i in picked:
             with sliced_relprop_state(model, i, B):
                 cache = vit_cache_from_model(model)
-                one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
-                assert torch.equal(one, maps[i:i + 1]), (i, float((one - maps[i:i + 1]).abs().max()))
+                if i in (0, 31, 63):       # batched == per-sample on the same cache, bitwise
+                    one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
+                    assert torch.equal(one, maps[i:i + 1]), (i, float((one - maps[i:i + 1]).abs().max()))
             ref = O.vit_relprop(oh[i:i + 1].cpu(), cache, num_heads=12, start_layer=1)
-            _assert_map(f"vit_b16_b64.oracle.map_sl1.{i}", maps[i:i + 1], ref["map"], norm_tol=2e-4, rel_tol=3e-4)
+            st = _assert_map(f"vit_b16_b64.oracle.map_sl1.{i}", maps[i:i + 1], ref["map"], norm_tol=1e-4, rel_tol=3e-4)
+            worst = max(worst, st["normalised_max_abs"])
+        record("vit_b16_b64.oracle.map_sl1.summary", samples=len(picked), of=B, worst_normalised_max_abs=worst,
+               bar=1e-4, start_layer=1)
         # conservation over the whole batch (same cache)
         cam = model.head.relprop(oh, alpha=1)
         cam = model.pool.relprop(cam.unsqueeze(1), alpha=1)
@@ -842,14 +895,16 @@ def _config2_body(model, lrp, producers):
     maps = lrp.generate_LRP(x, start_layer=1).clone()
     assert maps.shape == (B, 576) and torch.isfinite(maps).all()
     oh = _one_hot_of(model.head.Y.detach())
-    # oracle on sample 3's slice
-    i = 3
-    with sliced_relprop_state(model, i, B):
-        cache = vit_cache_from_model(model)
-        one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
-        assert torch.equal(one, maps[i:i + 1])
-    ref = O.vit_relprop(oh[i:i + 1].cpu(), cache, num_heads=16, start_layer=1)
-    _assert_map(f"vit_l16_384.{producers}.oracle.map_sl1", maps[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)
+    # the oracle on four samples' slices of the cache (~10 s of CPU each), held to the LITERAL
+    # north-star bar at start_layer = 1: min-max-normalised |delta| <= 1e-4 (measured 5e-7 ... 3e-6)
+    for i in sorted({3, B // 3, (2 * B) // 3, B - 1}):
+        with sliced_relprop_state(model, i, B):
+            cache = vit_cache_from_model(model)
+            if i == 3:
+                one = model.relprop(oh[i:i + 1], method="transformer_attribution", start_layer=1, alpha=1)
+                assert torch.equal(one, maps[i:i + 1])
+        ref = O.vit_relprop(oh[i:i + 1].cpu(), cache, num_heads=16, start_layer=1)
+        _assert_map(f"vit_l16_384.{producers}.oracle.map_sl1.{i}", maps[i:i + 1], ref["map"], norm_tol=1e-4, rel_tol=3e-4)
     # conservation over the whole batch
     cam = model.head.relprop(oh, alpha=1)
     cam = model.pool.relprop(cam.unsqueeze(1), alpha=1)
@@ -897,14 +952,15 @@ def _config3_body(model, producers):
     sums = cam.double().sum(dim=(1, 2)).cpu()
     record(f"bert_base_512.{producers}.conservation", min=float(sums.min()), max=float(sums.max()))
     assert (sums - 1.0).abs().max() < 2e-3
-    for i in (0, 1):       # padded, unpadded
+    for i in (0, 1, 14, 31):       # padded, unpadded, padded, unpadded: four of 32, literal 1e-4 bar
         with sliced_relprop_state(model, i, B):
             cache = bert_cache_from_model(model)
-            model.relprop(oh[i:i + 1], alpha=1)
-            one = gen.attribution_tail(start_layer=0)
-            assert torch.equal(one, out[i:i + 1]), float((one - out[i:i + 1]).abs().max())
+            if i < 2:
+                model.relprop(oh[i:i + 1], alpha=1)
+                one = gen.attribution_tail(start_layer=0)
+                assert torch.equal(one, out[i:i + 1]), float((one - out[i:i + 1]).abs().max())
         ref = O.bert_relprop(oh[i:i + 1].cpu(), cache, num_heads=12, start_layer=0)
-        _assert_map(f"bert_base_512.{producers}.oracle.map_sl0.{i}", out[i:i + 1], ref["map"], norm_tol=5e-4, rel_tol=1e-3)
+        _assert_map(f"bert_base_512.{producers}.oracle.map_sl0.{i}", out[i:i + 1], ref["map"], norm_tol=1e-4, rel_tol=3e-4)
 
 
 def test_zz_band_outliers_are_rare():
@@ -916,6 +972,16 @@ def test_zz_band_outliers_are_rare():
     out = [(n, r) for n, r in _BAND_LOG if r > BAND_K]
     med = sorted(r for _, r in _BAND_LOG)[len(_BAND_LOG) // 2]
     record("band_outliers", comparisons=len(_BAND_LOG), outliers=[[n, r] for n, r in out], median_ratio=med)
+    # how many of the reference's OWN maps are reproducible to the north-star bar?  (A cross-producer
+    # comparison can only assert 1e-4 where the reference reproduces itself that well; everything else is pinned through
+    # reference =bitwise= oracle on the CPU and HIP vs oracle <= 1e-4 on the same cache.)
+    import numpy as np
+    bands = np.load(os.path.join(os.path.dirname(__file__), "golden", "bands.npz"))
+    bn = {k[:-len(".band_norm")]: float(bands[k]) for k in bands.files if k.endswith(".band_norm")}
+    stable = sorted(k for k, v in bn.items() if v <= 1e-4)
+    record("reference_self_reproducibility", samples=len(bn), stable_at_1e_4=stable, fraction=len(stable) / max(1, len(bn)),
+           sl1_samples=sum(1 for k in bn if k.endswith(".sl1")), sl1_stable=sum(1 for k in stable if k.endswith(".sl1")),
+           median_band=float(np.median(list(bn.values()))))
     assert all(n in BAND_NAMED_OUTLIERS for n, _ in out), out
     assert len(out) <= max(1, len(_BAND_LOG) // 10), out
     assert med <= 1.0, med

@@ -150,3 +150,34 @@ def test_world2_gloo_sweep_layout_and_single_collective(tmp_path):
         total = sum(got[r]["calls"].values())
         assert total == 1 and set(got[r]["calls"]) <= {"all_gather", "all_gather_into_tensor"}, got[r]["calls"]
         assert torch.equal(got[r]["full"], stored), f"rank {r}: gathered maps are not the stores in global order"
+
+
+def test_sweep50k_layout_on_8_ranks():
+    """BASELINE.json configs[4]: 50 000 images, global batch 256 over 8 ranks -- every rank owns one
+    contiguous block of the global index space, walks it in batches of 32, the blocks tile the sweep exactly, and an image
+    depends on its GLOBAL index only (any shard layout sees the same data)."""
+    import bench
+    from transformer_explainability_amd import parallel
+    n, world, gb = 50_000, 8, 256
+    lay = parallel.sweep_layout(n, world, gb)
+    assert len(lay) == world and lay[0][0] == 0 and lay[-1][1] == n
+    seen = 0
+    for r, (lo, hi, batches) in enumerate(lay):
+        assert (lo, hi) == parallel.shard_range(n, r, world) and lo == seen
+        assert batches[0][0] == lo and batches[-1][1] == hi
+        assert all(b1 - b0 == gb // world for b0, b1 in batches[:-1]) and 0 < batches[-1][1] - batches[-1][0] <= gb // world
+        assert all(a[1] == b[0] for a, b in zip(batches, batches[1:]))
+        seen = hi
+    assert seen == n
+    with pytest.raises(ValueError):
+        parallel.sweep_layout(n, 3, gb)                       # 256 does not divide over 3 ranks
+    # the same global index gives the same image whoever generates it, and different indices differ
+    a = parallel.synthetic_image_on(31_337, "cpu", (3, 8, 8))
+    assert torch.equal(a, parallel.synthetic_image_on(31_337, "cpu", (3, 8, 8)))
+    assert not torch.equal(a, parallel.synthetic_image_on(31_338, "cpu", (3, 8, 8)))
+    # bench.py: the sweep's default run is the whole sweep in global batches; per-rank batch = 256 / world
+    args = bench.parse_args(["--config", "sweep50k"])
+    assert args.steps == -(-bench.SWEEP_IMAGES // bench.SWEEP_GLOBAL_BATCH) == 196
+    assert bench.parse_args([]).steps == 5
+    # a single rank is left alone by the core pinning; N ranks get disjoint slices
+    assert parallel.pin_rank_to_cores(0, 1) == 0

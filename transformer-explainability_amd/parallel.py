@@ -70,3 +70,48 @@ def synthetic_image(global_index: int, shape=(3, 224, 224), seed: int = 1) -> to
     """Deterministic synthetic sample keyed by its GLOBAL index, so any shard layout sees the same data."""
     g = torch.Generator().manual_seed(seed * 1_000_003 + global_index)
     return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def pin_rank_to_cores(local_rank: int, ranks_on_node: int) -> int:
+    """One process per GPU: give each rank its own slice of the host cores this process may run on (affinity / cgroup aware)
+    and size torch's intra-op pool to it, so that eight ranks capturing / enqueueing at once do not fight for the same cores
+    (the host side of a step is ~1000 launches; an oversubscribed host shows up as stream gaps on every GPU).  Returns the
+    number of cores the rank was given (0 = left alone: single rank, or fewer cores than ranks)."""
+    if ranks_on_node <= 1:
+        return 0
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return 0
+    per = len(cores) // ranks_on_node
+    if per < 1:
+        return 0
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return 0
+    os.environ["OMP_NUM_THREADS"] = str(per)
+    torch.set_num_threads(per)
+    return per
+
+
+def sweep_layout(n_items: int, world: int, global_batch: int):
+    """The 50 000-image sweep of BASELINE.json configs[4] (reference: baselines/ViT/generate_visualizations.py:27-100 over the
+    ImageNet validation set) on `world` ranks: rank r owns the contiguous block shard_range(n_items, r, world) and walks it in
+    batches of global_batch / world.  Returns [(lo, hi, [(b_lo, b_hi), ...]) per rank] in GLOBAL sample indices."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} does not divide over {world} ranks")
+    per = global_batch // world
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(n_items, r, world)
+        out.append((lo, hi, [(s, min(s + per, hi)) for s in range(lo, hi, per)]))
+    return out
+
+
+def synthetic_image_on(global_index: int, device, shape=(3, 224, 224), seed: int = 1) -> torch.Tensor:
+    """synthetic_image generated ON `device` (a 50 000-image sweep cannot afford 1 ms of host randn per image): keyed by the
+    GLOBAL index alone, so every shard layout on the same kind of device sees the same image."""
+    g = torch.Generator(device=device).manual_seed(seed * 1_000_003 + global_index)
+    return torch.randn(shape, generator=g, dtype=torch.float32, device=device)

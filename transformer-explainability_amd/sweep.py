@@ -166,8 +166,9 @@ class SaliencySweep:
         self.method, self.vis_class, self.is_ablation = method, vis_class, bool(is_ablation)
         self.lrp, self.orig_lrp, self.baselines, self.device = lrp, orig_lrp, baselines, device
 
-    def explain(self, data, target=None):
-        """One batch of normalised images -> min-max normalised maps [B,1,H,W] at image resolution (:60-98)."""
+    def explain(self, data, target=None, return_maps=False):
+        """One batch of normalised images -> min-max normalised maps [B,1,H,W] at image resolution (:60-98);
+        return_maps: also the patch-level maps [B, g*g] they were up-sampled from."""
         index = target if self.vis_class == "target" else None                   # :62-64
         m = self.method
         if m == "rollout":
@@ -189,8 +190,10 @@ class SaliencySweep:
         g = int(round(res.shape[1] ** 0.5))
         if g == H:                                   # full_lrp is already at pixel resolution (:95): min-max only
             lo, hi = res.amin(dim=1, keepdim=True), res.amax(dim=1, keepdim=True)
-            return ((res - lo) / (hi - lo)).reshape(B, 1, H, H)
-        return ops.heatmap(res, scale=H // g, normalise=True)       # :96-97: bilinear x16 + min-max, one launch
+            heat = ((res - lo) / (hi - lo)).reshape(B, 1, H, H)
+        else:
+            heat = ops.heatmap(res, scale=H // g, normalise=True)   # :96-97: bilinear x16 + min-max, one launch
+        return (heat, res) if return_maps else heat
 
     def run(self, loader_batches, store, rank=0, world=1):
         """loader_batches: iterable of (data [B,3,H,W] in [0,1], target [B]) covering THIS rank's samples in order."""
