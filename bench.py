@@ -121,6 +121,11 @@ def parse_args(argv=None):
                          "split-operand bf16 kernel (te_gemm_x6_f32) instead of the stock fp32 GEMM: all (default; 73.3 vs "
                          "78.9 ms per ViT-B step), auto = only where the operand is narrow and the output wide "
                          "(ops.gemm_x6_wanted), off; the fp32-MFMA comparison run of the line always uses the stock GEMMs")
+    ap.add_argument("--rules", choices=["ours", "lrp"], default="ours",
+                    help="ViT configurations: the rule library the model is built over -- ours = modules/layers_ours.py "
+                         "(baselines/ViT/ViT_LRP.py, method transformer_attribution: the headline), lrp = modules/layers_lrp.py "
+                         "(baselines/ViT/ViT_orig_LRP.py, method grad: separate denominators per sign, 4 instead of 3 products per "
+                         "Linear rule -- te_linear_relprop_x6_general_f32)")
     ap.add_argument("--x6-tile", choices=["auto", "128", "256"], default="auto",
                     help="tile geometry of the x6 Linear kernels (measurement knob: the maps do not depend on it)")
     ap.add_argument("--producers", choices=["stock", "fused"], default="fused",
@@ -221,6 +226,10 @@ KERNEL_GROUPS = {
     "linear_x6_zpass": ("x6_kernel<2, MODE_Z>", "Linear.relprop Z-pass from the forward output on bf16 MFMAs (6 products), "
                                                 "S written as bf16 planes, layers_ours.py:216-219"),
     "linear_x6_split": ("zero_words_kernel + split_kernel<OP_ABS>", "|X| -> three bf16 planes in MFMA-fragment order"),
+    "linear_x6_general": ("split_kernel<OP_POS / OP_NEG> + x6_kernel<., MODE_Z1> x 2 + x6_kernel<., MODE_X> x 2 (variant lrp) | "
+                          "x6_kernel<., MODE_Z / MODE_C / MODE_ZI / MODE_CI> (ours, alpha != 1)",
+                          "Linear.relprop for variant lrp / alpha != 1 on bf16 MFMAs: one-sided products, 24 (lrp) or 18 (ours) "
+                          "bf16 product units of 2*T*in*out per half, layers_lrp.py:188-211, layers_ours.py:225-228"),
     "linear_forward_x6": ("split_kernel<OP_ID> + x6_kernel<2, MODE_G>", "producer: y = x W^T + b (nn.Linear, "
                           "layers_ours.py:207) on bf16 MFMAs, 6 products of 2*T*in*out flops"),
     "linear_backward_x6": ("split_kernel<OP_ID> + x6_kernel<2, MODE_G>", "producer: d_x = d_y W on bf16 MFMAs"),
@@ -307,11 +316,18 @@ class Workload:
             if SWEEP_GLOBAL_BATCH % world:
                 sys.exit(f"--config sweep50k: the global batch of {SWEEP_GLOBAL_BATCH} does not divide over {world} ranks")
             self.B = B = args.batch or SWEEP_GLOBAL_BATCH // world
+        self.rules = getattr(args, "rules", "ours")
         if args.config.startswith("vit") or self.sweep:
-            if args.config in ("vit_b16_224", "sweep50k"):
-                model, side = vit.vit_base_patch16_224().eval(), 224
+            if self.rules == "lrp":          # baselines/ViT/ViT_orig_LRP.py: the same architecture over the lrp rule library
+                from transformer_explainability_amd import rules_lrp
+                ns = vit.make_vit_module(rules_lrp)
+                mk_b, mk_l = ns["vit_base_patch16_224"], ns["vit_large_patch16_224"]
             else:
-                model, side = vit.vit_large_patch16_224(img_size=384).eval(), 384
+                mk_b, mk_l = vit.vit_base_patch16_224, vit.vit_large_patch16_224
+            if args.config in ("vit_b16_224", "sweep50k"):
+                model, side = mk_b().eval(), 224
+            else:
+                model, side = mk_l(img_size=384).eval(), 384
             with torch.no_grad():          # non-trivial biases / LayerNorm scales so every path is exercised
                 for _, p in model.named_parameters():
                     if p.dim() == 1:
@@ -370,7 +386,8 @@ class Workload:
             self.last_heat = heat
             return maps
         if self.name.startswith("vit"):
-            return self.gen.generate_LRP(inputs[0], method="transformer_attribution", start_layer=self.start_layer)
+            return self.gen.generate_LRP(inputs[0], method="transformer_attribution" if self.rules == "ours" else "grad",
+                                         start_layer=self.start_layer)
         return self.gen.generate_LRP(input_ids=inputs[0], attention_mask=inputs[1], start_layer=self.start_layer)
 
     def eager_serial(self, *inputs):
@@ -436,15 +453,17 @@ def cpu_baseline(args, wl):
     if kind == "reference":
         if is_vit:
             mods = rh.load_reference_vit()
+            ref_mod = mods["ViT_LRP"] if wl.rules == "ours" else mods["ViT_orig_LRP"]
             if wl.name in ("vit_b16_224", "sweep50k"):
-                model = mods["ViT_LRP"].vit_base_patch16_224(pretrained=False).eval()
+                model = ref_mod.vit_base_patch16_224(pretrained=False).eval()
             else:
-                model = mods["ViT_LRP"].vit_large_patch16_224(pretrained=False, img_size=384).eval()
+                model = ref_mod.vit_large_patch16_224(pretrained=False, img_size=384).eval()
             model.load_state_dict(wl.cpu_state)
             gen = mods["gen"].LRP(model)
-            run = lambda i: gen.generate_LRP(xs[i:i + 1], method="transformer_attribution",    # noqa: E731
-                                             start_layer=wl.start_layer)
-            what = "reference LRP.generate_LRP (baselines/ViT/ViT_explanation_generator.py:25-41)"
+            meth = "transformer_attribution" if wl.rules == "ours" else "grad"
+            run = lambda i: gen.generate_LRP(xs[i:i + 1], method=meth, start_layer=wl.start_layer)    # noqa: E731
+            what = (f"reference LRP.generate_LRP over {'ViT_LRP' if wl.rules == 'ours' else 'ViT_orig_LRP'} "
+                    f"(baselines/ViT/ViT_explanation_generator.py:25-41, method {meth})")
         else:
             mods = rh.load_reference_bert()
             from transformers import BertConfig
@@ -568,12 +587,11 @@ def main():
     if not args.no_roofline:
         ops.KERNEL_TIMER = timer
 
-    if args.inflight > 1 and not os.environ.get("TE_ALLOW_INFLIGHT"):
-        # Measured in round 3: two step graphs replayed concurrently on two streams stop making progress on this ROCm
-        # build (every run with --inflight 2 / 3 ran into its 300 s limit; not diagnosed: each attempt costs minutes of
-        # GPU time).  Refuse instead of hanging the box.
-        sys.exit("bench.py: --inflight > 1 is disabled (concurrent step graphs hang, see DESIGN.md section 7); "
-                 "set TE_ALLOW_INFLIGHT=1 to try it anyway")
+    # --inflight N: round 3 refused it (two step graphs in flight "hung": every expired hand-over wait of the x6 kernels cost
+    # seconds, and they expired one after the other).  Since round 4 the waits are bounded at 250 ms, fail fast once one has
+    # expired and end in a TeError below, so the option is safe to use; measured on the MI355X it is worth +1.6 % with two
+    # steps in flight and nothing with three (profiles/r04_inflight2.log) -- relprop beside the backward pass already fills
+    # most of the gaps -- so the default stays one step in flight.
     lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
 
@@ -727,7 +745,8 @@ def main():
         fused_on = args.producers == "fused" and ops.attention_forward_supported(wl.tokens, 64)
         fused_note = "attention blocks on the HIP producer kernels" if fused_on else "stock kernels throughout"
         line = {
-            "metric": f"relevance {wl.noun}/sec ({wl.title}, batch {B} per GPU, generate_LRP transformer_attribution)",
+            "metric": f"relevance {wl.noun}/sec ({wl.title}, batch {B} per GPU, generate_LRP "
+                      f"{'transformer_attribution' if getattr(wl, 'rules', 'ours') == 'ours' else 'grad over the lrp rule library (ViT_orig_LRP)'})",
             "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": X6_DTYPE if args.linear == "x6" else "f32", "data": "synthetic",
@@ -754,6 +773,7 @@ def main():
                                                 "PyTorch TunableOp, tuned in this run" if tuned else "PyTorch default"),
                        "linear_relprop": ("x6: bf16 MFMAs on three-way split fp32 operands, six partial products, fp32 "
                                           "accumulation" if args.linear == "x6" else "fp32 MFMA"),
+                       "rule_library": getattr(wl, "rules", "ours"),
                        "linear_forward_backward": (("stock fp32 GEMMs, except on the x6 kernel (te_gemm_x6_f32): "
                                                     + {"auto": "forward products and input gradients with K <= 1024 and "
                                                                "M >= 2 K (qkv / fc1 forward, fc2 input gradient)",
@@ -770,15 +790,15 @@ def main():
         try:   # HBM-side bytes per C-pass launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
                # MI355X guide's gfx950 correction); only valid for the workload they were collected on
             if args.config == "vit_b16_224" and B == 64:
-                cands = (("r03_linear_x6_traffic_pmc.json",) if args.linear == "x6" else
+                cands = (("r04_linear_x6_traffic_pmc.json", "r03_linear_x6_traffic_pmc.json") if args.linear == "x6" else
                          ("r03_linear_traffic_pmc.json", "r02_linear_traffic_pmc.json", "r01_linear_traffic_pmc.json"))
                 for cand in cands:
                     path = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(path):
                         with open(path) as f:
                             tr = json.load(f)
-                        cps = [v["traffic_bytes"] for k, v in tr.items() if k.endswith(".cpass")]
-                        traffic = sum(cps) / len(cps)
+                        cps = [(v["traffic_bytes"], v.get("dispatches", 1)) for k, v in tr.items() if k.endswith(".cpass")]
+                        traffic = sum(t * n for t, n in cps) / sum(n for _, n in cps)      # per launch, all C-pass shapes
                         traffic_src = cand
                         break
         except (OSError, ValueError, KeyError):
@@ -815,6 +835,16 @@ def main():
                                         "2*T*in*out flops; S leaves as bf16 planes)",
                               "achieved": x6z["tflops"], "frac": x6z["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                               "avg_launch_us": x6z["avg_us"]} if x6z else None,
+                    "kernels": kernel_table(timer), "kernels_note": kernels_note}
+        elif timer.summary("linear_x6_general", 0.0):
+            x6g = timer.summary("linear_x6_general", 0.0)
+            roof = {"bound": "mfma", "mfma_dtype": "bf16",
+                    "kernel": "te_linear_relprop_x6_general_f32 (Linear.relprop of the lrp rule library: four one-sided x6 "
+                              "products per rule, x6_kernel<., MODE_Z1> and x6_kernel<., MODE_X>, + the X+ / X- split)",
+                    "achieved": x6g["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": x6g["tflops"] / MFMA_BF16_PEAK_TFLOPS, "fp32_equivalent_tflops": x6g["tflops"] / 6.0,
+                    "traffic": None, "launches_timed": x6g["launches"], "avg_launch_us": x6g["avg_us"],
+                    "executed_bf16_flops_per_launch_avg": x6g["flops_per_launch"],
                     "kernels": kernel_table(timer), "kernels_note": kernels_note}
         elif cp:
             roof = {"bound": "mfma", "mfma_dtype": "f32",

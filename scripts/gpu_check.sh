@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU trip (round 3): parity tests, smoke, the bench line, rocprofv3 kernel stats of the same command (and of the same
+# One GPU trip (rounds 3-4): parity tests, smoke, the bench line, rocprofv3 kernel stats of the same command (and of the same
 # step run serially: --overlap-backward off, what the roofline block's HIP-event times are comparable to), PMC passes of the
 # x6 Linear kernels, the other two configurations, the self-launching 2-rank path on the one-GPU rig.
 #   gpurun --timeout 1800 -- 'bash scripts/gpu_check.sh'      (logs land in gpurun_out/; SKIP_TESTS=1 skips pytest)

@@ -1,7 +1,8 @@
 #!/bin/bash
-# SQ counters, L2 hit rate and HBM-side bytes of the x6 Linear.relprop kernels at the ViT-B batch-64 shapes (separate
-# rocprofv3 --pmc passes with --kernel-trace only; traffic = 2 * FETCH_SIZE + WRITE_SIZE KB per the guide's gfx950 note).
-#   gpurun --timeout 900 -- 'bash scripts/x6_pmc.sh'   -> gpurun_out/x6_pmc_summary.csv
+# SQ counters, L2 hit rate and HBM-side bytes of the x6 Linear kernels at the ViT-B/16 batch-64 shapes: the rule's Z- and C-pass
+# AND the layers' own forward / input-gradient products (benchmarks/x6_variants.py --variants base --iters 1: three launches
+# of each per shape), separate rocprofv3 --pmc passes with --kernel-trace only; traffic = (2 * FETCH_SIZE + WRITE_SIZE) KB per
+# the guide's gfx950 note.   gpurun --timeout 900 -- 'bash scripts/x6_pmc.sh'   -> gpurun_out/x6_pmc_summary.csv, x6_traffic_pmc.json
 mkdir -p gpurun_out; export TMPDIR=/tmp; ROOT=$PWD
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"
 P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA"
@@ -13,35 +14,51 @@ i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5" "$P6"; do
   i=$((i+1)); rm -rf gpurun_out/x6pmc$i
   ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $P -f csv -d "$ROOT/gpurun_out/x6pmc$i" -o x6 -- \
-      python "$ROOT/benchmarks/x6_study.py" --once > "$ROOT/gpurun_out/x6pmc$i.log" 2>&1 )
+      python "$ROOT/benchmarks/x6_variants.py" --variants base --iters 1 > "$ROOT/gpurun_out/x6pmc$i.log" 2>&1 )
 done
 python - <<'PY'
-import csv, glob, collections, re
+import csv, glob, collections, json, re
+MODES = {0: "zpass", 1: "cpass", 2: "gemm", 3: "zpass_inhibitor", 4: "zpass_onesided", 5: "cpass_inhibitor", 6: "masked_product"}
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/x6pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"x6_kernel<(\d), *(\d)", r["Kernel_Name"])
-        if not m:
-            m2 = re.search(r"split_kernel", r["Kernel_Name"])
-            if not m2:
-                continue
+        m = re.search(r"x6_kernel<(\d), *(\d), *(\d), *(\d), *(\d)", r["Kernel_Name"])
+        if m:
+            wm, mode, _, nst, ks = (int(g) for g in m.groups())
+            key = f"{MODES.get(mode, mode)}_wm{wm}_ks{ks}_grid{r.get('Grid_Size', '')}"
+        elif "split_kernel" in r["Kernel_Name"]:
             key = "split"
         else:
-            key = ("zpass" if m.group(2) == "0" else "cpass") + f"_wm{m.group(1)}_grid{r.get('Grid_Size','')}_lds{r.get('LDS_Block_Size','')}"
+            continue
         rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = ["kernel,counter,mean_per_dispatch,dispatches"]
+js = {"_note": "rocprofv3 --pmc passes (separate runs, --kernel-trace only; scripts/x6_pmc.sh) over benchmarks/x6_variants.py "
+               "--variants base --iters 1: the Z-pass, the C-pass and the forward / input-gradient product of each of the four "
+               "ViT-B/16 batch-64 Linear shapes (T = 12608), three launches each; per-launch means per kernel instance (tile "
+               "geometry wm 2 / 1 / 0 = 256x256 / 128x256 / 128x128, ks = K segments, grid = threads).  traffic_bytes = (2 * "
+               "FETCH_SIZE + WRITE_SIZE) KB * 1024 (MI355X guide: FETCH_SIZE counts 64-B units as 32 B on gfx950).  "
+               "Keys: workload.kernel instance.pass"}
 for k, cs in sorted(rows.items()):
     for c, v in sorted(cs.items()):
         out.append(f"{k},{c},{sum(v) / len(v):.6g},{len(v)}")
-    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        f_kb, w_kb = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]), sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
-        out.append(f"{k},traffic_bytes(2*FETCH+WRITE KB),{(2 * f_kb + w_kb) * 1024:.6g},")
-    if "TCC_HIT_sum" in cs:
+    mean = lambda n: (sum(cs[n]) / len(cs[n])) if cs.get(n) else None      # noqa: E731
+    e = {}
+    if cs.get("FETCH_SIZE") and cs.get("WRITE_SIZE"):
+        e["traffic_bytes"] = (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024
+        e["fetch_size_kb"], e["write_size_kb"] = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+        out.append(f"{k},traffic_bytes(2*FETCH+WRITE KB),{e['traffic_bytes']:.6g},")
+    if cs.get("TCC_HIT_sum"):
         h, m = sum(cs["TCC_HIT_sum"]), sum(cs["TCC_MISS_sum"])
-        out.append(f"{k},l2_hit_rate,{h / max(h + m, 1):.4g},")
-    if "SQ_INSTS_VALU" in cs and "SQ_INSTS_MFMA" in cs:
-        out.append(f"{k},valu_per_mfma,{sum(cs['SQ_INSTS_VALU']) / max(sum(cs['SQ_INSTS_MFMA']), 1):.4g},")
+        e["l2_hit_rate"] = h / max(h + m, 1)
+        out.append(f"{k},l2_hit_rate,{e['l2_hit_rate']:.4g},")
+    if cs.get("SQ_INSTS_VALU") and cs.get("SQ_INSTS_MFMA") and sum(cs["SQ_INSTS_MFMA"]) > 0:
+        e["valu_per_mfma"] = sum(cs["SQ_INSTS_VALU"]) / sum(cs["SQ_INSTS_MFMA"])
+        out.append(f"{k},valu_per_mfma,{e['valu_per_mfma']:.4g},")
+    e["mfma_busy_cycles"], e["busy_cycles"], e["lds_bank_conflict"] = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("SQ_BUSY_CYCLES"), mean("SQ_LDS_BANK_CONFLICT")
+    e["dispatches"] = max((len(v) for v in cs.values()), default=0)
+    js[f"vit_b16_b64.{k}.{k.split('_wm')[0]}"] = e
 open("gpurun_out/x6_pmc_summary.csv", "w").write("\n".join(out) + "\n")
-print("\n".join(out))
+json.dump(js, open("gpurun_out/x6_traffic_pmc.json", "w"), indent=1)
+print("\n".join(l for l in out if "traffic" in l or "hit_rate" in l or "valu_per" in l))
 PY
 tail -3 gpurun_out/x6pmc1.log
