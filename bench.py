@@ -221,18 +221,18 @@ def mfma_peak(name):
 
 KERNEL_GROUPS = {
     # timer name: (device kernels, reference rule)
-    "linear_x6_cpass": ("x6_kernel<2, MODE_C>", "Linear.relprop C-pass on bf16 MFMAs (P+ and P- side by side: 12 bf16 "
+    "linear_x6_cpass": ("x6_kernel<WM, MODE_C, 0, 2, 1> (rocprofv3 prints the numbers: <2, 1, 0, 2, 1>)", "Linear.relprop C-pass on bf16 MFMAs (P+ and P- side by side: 12 bf16 "
                                                 "products of 2*T*in*out flops), layers_ours.py:220-225"),
-    "linear_x6_zpass": ("x6_kernel<2, MODE_Z>", "Linear.relprop Z-pass from the forward output on bf16 MFMAs (6 products), "
+    "linear_x6_zpass": ("x6_kernel<WM, MODE_Z, 0, 2, KSPLIT> (<2, 0, 0, 2, 1>; fc2: <2, 0, 0, 2, 2>; proj: <0, 0, 0, 2, 1>)", "Linear.relprop Z-pass from the forward output on bf16 MFMAs (6 products), "
                                                 "S written as bf16 planes, layers_ours.py:216-219"),
     "linear_x6_split": ("zero_words_kernel + split_kernel<OP_ABS>", "|X| -> three bf16 planes in MFMA-fragment order"),
     "linear_x6_general": ("split_kernel<OP_POS / OP_NEG> + x6_kernel<., MODE_Z1> x 2 + x6_kernel<., MODE_X> x 2 (variant lrp) | "
                           "x6_kernel<., MODE_Z / MODE_C / MODE_ZI / MODE_CI> (ours, alpha != 1)",
                           "Linear.relprop for variant lrp / alpha != 1 on bf16 MFMAs: one-sided products, 24 (lrp) or 18 (ours) "
                           "bf16 product units of 2*T*in*out per half, layers_lrp.py:188-211, layers_ours.py:225-228"),
-    "linear_forward_x6": ("split_kernel<OP_ID> + x6_kernel<2, MODE_G>", "producer: y = x W^T + b (nn.Linear, "
+    "linear_forward_x6": ("split_kernel<OP_ID> + x6_kernel<WM, MODE_G, 0, 2, KSPLIT>", "producer: y = x W^T + b (nn.Linear, "
                           "layers_ours.py:207) on bf16 MFMAs, 6 products of 2*T*in*out flops"),
-    "linear_backward_x6": ("split_kernel<OP_ID> + x6_kernel<2, MODE_G>", "producer: d_x = d_y W on bf16 MFMAs"),
+    "linear_backward_x6": ("split_kernel<OP_ID> + x6_kernel<WM, MODE_G, 0, 2, KSPLIT>", "producer: d_x = d_y W on bf16 MFMAs"),
     "linear_cpass": ("linear_k2_kernel<0,false,false>", "Linear.relprop C-pass, layers_ours.py:220-225"),
     "linear_zpass_fwd": ("linear_k1_kernel<ZM_FWD>", "Linear.relprop Z-pass from the forward output, layers_ours.py:216-219"),
     "linear_zpass": ("linear_k1_kernel<ZM_OURS>", "Linear.relprop Z-pass (two products), layers_ours.py:216-219"),
@@ -256,7 +256,11 @@ KERNEL_GROUPS = {
     "clone": ("clone_kernel / clone_scaled_kernel", "Clone.relprop, layers_ours.py:151-169"),
     "headmean": ("headmean_flat_kernel", "mean_h max(grad * attn_cam, 0), ViT_LRP.py:359-366"),
     "rollout_row0_chain": ("rollout_row_step_kernel x (L - start) + finish", "compute_rollout_attention row 0, "
-                                                                            "ViT_LRP.py:38-49,369"),
+                           "ViT_LRP.py:38-49,369 -- NOT an MFMA kernel on the hot path: the generators read row 0 of the "
+                           "rollout only, which is a chain of L - start vector x matrix steps (3.4 MB per ViT-B map instead of "
+                           "0.15 GFLOP of (N x N)(N x N) products); 12 launches of ~5 us, launch-bound, so the HBM fraction "
+                           "below says nothing about the kernel.  The MFMA full-matrix chain (rollout_bmm_mfma_kernel) serves "
+                           "method='rollout' / compute_rollout_attention callers and is timed as rollout_matrix_chain"),
     "rollout_matrix_chain": ("rollout_prep + rollout_bmm_mfma_kernel x (L-1-start)", "compute_rollout_attention"),
 }
 

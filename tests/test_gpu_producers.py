@@ -216,8 +216,10 @@ def test_linear_rule_reuses_forward_planes():
         lin(x)
         cache = rules.x6_cache(lin)
         assert "x_abs_planes" in cache and cache["x_abs_planes"][0][0] == x.data_ptr()
+        kept = cache["x_abs_planes"]
         with_planes = lin.relprop(R, 1.0)
-        kept = cache.pop("x_abs_planes")
+        # consumed once (6 B per input element must not stay parked in the layer after its rule has run)
+        assert "x_abs_planes" not in cache
         own_split = lin.relprop(R, 1.0)
         assert torch.equal(with_planes, own_split)
         cache["x_abs_planes"] = kept
