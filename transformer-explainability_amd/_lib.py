@@ -17,6 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TE_RELPROP_LIB") or os.path.join(_PKG, "lib", "libte_relprop.so")
 
 TE_OK = 0
+MIN_LIB_VERSION = 400      # te_version(): 0.4.0, the round-4 ABI (x6 entry points take flags + a status word)
 TE_ERR_UNSUPPORTED = -3
 TE_VARIANT_OURS = 0
 TE_VARIANT_LRP = 1
@@ -147,6 +148,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.te_version() < MIN_LIB_VERSION:      # a stale in-tree build: argument lists changed (x6 flags / status words)
+        raise TeError(f"{LIB_PATH} is version {lib.te_version()}, this package needs >= {MIN_LIB_VERSION}: rebuild it "
+                      f"(python transformer-explainability_amd/build.py --force)")
     _lib = lib
     return lib
 

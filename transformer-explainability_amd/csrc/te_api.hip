@@ -3,7 +3,7 @@
 
 #include <string.h>
 
-extern "C" int te_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int te_version(void) { return 400; /* 0.4.0: round 4 -- x6 entry points take flags + a status word; the general rule */ }
 
 extern "C" const char* te_status_string(int status) {
   switch (status) {
