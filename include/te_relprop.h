@@ -292,6 +292,9 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
 #define TE_X6_TILE_128x128 3
 #define TE_X6_STAGES_3 0x100
 #define TE_X6_TEST_DROP_HANDOVER 0x200
+#define TE_X6_KSPLIT 0x8000            /* study, off by default: products with K >= 1536 and <= 768 weight rows as two K segments per
+                                          output (two k-ordered chains, summed once).  It changes the bits: set it for every
+                                          launch of a process or for none.  Measured: no gain in the step */
 #define TE_X6_TEST_SMALL_GRID 0x4000   /* tests: a persistent grid of 16 workgroups, so that small shapes get stream-K cuts */
 #define TE_X6_TILE_Z_SHIFT 10
 #define TE_X6_TILE_C_SHIFT 12

@@ -261,6 +261,18 @@ def test_linear_x6_schedules_are_bitwise_equal(T, in_f, out_f):
                     got = ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)
                     assert torch.equal(got, base), (tile, st, grid)
                     assert torch.equal(ops.gemm_x6(Xd, wp, bd, out_f), gbase), (tile, st, grid)
+        # the K-split study (TE_X6_KSPLIT: two k-ordered chains per output for K >= 1536 into <= 768 weight rows; off by
+        # default, it changes the bits): within the setting every geometry and schedule agrees bit for bit as well
+        if in_f >= 1536 and out_f <= 768:
+            ops.X6_TILE, ops.X6_FLAGS = 0, ops.TE_X6_KSPLIT
+            kbase = ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)
+            gk = ops.gemm_x6(Xd, wp, bd, out_f)
+            check(f"linear_x6_ksplit_vs_single_chain({T},{in_f},{out_f})", kbase, base, 1e-5)
+            for tile in (1, 2, 3):
+                for grid in (0, ops.TE_X6_TEST_SMALL_GRID):
+                    ops.X6_TILE, ops.X6_FLAGS = tile, ops.TE_X6_KSPLIT | grid
+                    assert torch.equal(ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache), kbase), (tile, grid)
+                    assert torch.equal(ops.gemm_x6(Xd, wp, bd, out_f), gk), (tile, grid)
         # per-pass pins: Z on 128-row tiles, C on 256-row tiles and the other way round
         ops.X6_TILE = 0
         for fl in ((1 << ops.TE_X6_TILE_Z_SHIFT) | (2 << ops.TE_X6_TILE_C_SHIFT),

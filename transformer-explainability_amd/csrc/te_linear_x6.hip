@@ -905,17 +905,23 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
 inline size_t planes_bytes(int64_t rows, int64_t K) {
   return (size_t)te_ceil_div(rows, 32) * 32 * (size_t)K * 6;
 }
-// Fixed K split (the same for every tile geometry, batch size and schedule: a property of the layer's shape only, so
-// results stay bitwise batch-invariant and geometry-invariant).  Products with a long K and few weight rows -- out_f = 768
-// against K = 2304 / 3072: fc2's forward, the input gradients of qkv and fc1, fc2's Z-pass -- are 150 tiles of 256 x 256
-// for 256 CUs, and a tile is a SEQUENTIAL chain of K / 16 steps however it is scheduled: 144-192 steps of ~1.9 us were the
-// floor of those launches.  Two chains per output halve the floor and double the work items.
-inline int kseg_rule(int64_t K, int64_t rows_w) { return (K >= 1536 && rows_w <= 768 && (K / 16) % 2 == 0) ? 2 : 1; }
+// Fixed K split -- a STUDY, off by default (the flag TE_X6_KSPLIT turns it on; it changes which chains an output is summed
+// from, i.e. the bits: a caller sets it for every launch of a process or for none).  Products with a long K and few weight rows --
+// out_f = 768 against K = 2304 / 3072: fc2's forward, the input gradients of qkv and fc1, fc2's Z-pass -- are 150 tiles
+// of 256 x 256 for 256 CUs, and a tile is a SEQUENTIAL chain of K / 16 steps however it is scheduled.  Two chains per output
+// (the same two for every tile geometry, batch size and schedule: a property of the layer's shape only, so results stay
+// bitwise batch- and geometry-invariant) halve that floor and double the work items.  Measured:
+// isolated launches gain 10-17 % over 128 x 256 tiles, but only 5 % over the 128 x 128 geometry that shipped with it, and
+// IN THE STEP nothing (ViT-B/16: 893 vs 896 maps/s, same box, A B A B) or less than nothing (BERT-512: 286 vs 292
+// sequences/s: at T = 16 384 the un-split 128 x 128 launch is exactly one tile per workgroup slot) -- the CUs a narrow
+// launch leaves idle are used by the other stream of the step anyway.  Not shipped.
+inline int kseg_shape(int64_t K, int64_t rows_w) { return (K >= 1536 && rows_w <= 768 && (K / 16) % 2 == 0) ? 2 : 1; }
+inline int kseg_rule(int64_t K, int64_t rows_w, int flags) { return (flags & TE_X6_KSPLIT) ? kseg_shape(K, rows_w) : 1; }
 inline size_t seg_part_bytes(int64_t T, int64_t K, int64_t rows_w) {       // accumulators of segment 0, any geometry
-  return kseg_rule(K, rows_w) == 2 ? te_align_up((size_t)te_ceil_div(T, 256) * 256 * (size_t)rows_w * 4, 256) : 0;
+  return kseg_shape(K, rows_w) == 2 ? te_align_up((size_t)te_ceil_div(T, 256) * 256 * (size_t)rows_w * 4, 256) : 0;
 }
 inline size_t seg_flag_words(int64_t T, int64_t K, int64_t rows_w) {       // one per tile of the smallest geometry, x 1024
-  return kseg_rule(K, rows_w) == 2 ? te_align_up((size_t)te_ceil_div(T, 128) * (size_t)(rows_w / 128), 1024) : 0;
+  return kseg_shape(K, rows_w) == 2 ? te_align_up((size_t)te_ceil_div(T, 128) * (size_t)(rows_w / 128), 1024) : 0;
 }
 inline size_t seg_region_bytes(int64_t T, int64_t K, int64_t rows_w) {
   return seg_part_bytes(T, K, rows_w) + seg_flag_words(T, K, rows_w) * 4;
@@ -981,7 +987,7 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
 template <int MODE>
 int launch_x6_mode(int wm, bool three_stages, const X6Params& p, hipStream_t stream) {
   if constexpr (MODE != MODE_C && MODE != MODE_CI) {
-    if (p.seg_part && p.seg_flags && kseg_rule((int64_t)p.nks * 16, p.rows_w) == 2) {
+    if (p.seg_part && p.seg_flags && kseg_shape((int64_t)p.nks * 16, p.rows_w) == 2) {
       if (wm == 2) return launch_x6<2, MODE, 0, 2, 2>(p, stream);
       if (wm == 1) return launch_x6<1, MODE, 0, 2, 2>(p, stream);
       return launch_x6<0, MODE, 0, 2, 2>(p, stream);
@@ -1009,7 +1015,8 @@ inline int choose_geo(int wm_max, int64_t T, int64_t rows_w, int pin, int min_ti
   // every CU a tile ...
   if (wm_max == 2 && t256 * (rows_w / 256) * ksplit >= min_tiles_256) return 2;       // (work items: tiles x K segments)
   // ... 128 x 256 (two workgroups per CU) while there are at least ~1.75 tiles per CU, else 128 x 128 (three per CU)
-  if (small_ok && t256 * (rows_w / 128) * ksplit < 448) return 0;
+  static const bool no_small = [] { const char* e = getenv("TE_X6_SMALL_TILES"); return e && atoi(e) == 0; }();      // (A/B knob)
+  if (small_ok && !no_small && t256 * (rows_w / 128) * ksplit < 448) return 0;
   return 1;
 }
 
@@ -1104,7 +1111,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
                               int64_t T, int64_t K, int64_t M, int flags, unsigned* status, void* ws, size_t ws_bytes,
                               te_stream_t stream_) {
   if ((!X && !x_planes) || !w_planes || !out) return TE_ERR_INVALID_ARG;
-  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
   if (!te_gemm_x6_supported(T, K, M)) return TE_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < te_gemm_x6_workspace_bytes(T, K, M) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
   if ((X && !te_aligned16(X)) || !te_aligned16(out) || !te_aligned16(w_planes) || (bias && !te_aligned16(bias)) ||
@@ -1121,7 +1128,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   zero_words_kernel<<<dim3(kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
   float* seg_part = nullptr;
   unsigned* seg_flags = nullptr;
-  if (kseg_rule(K, M) == 2) {
+  if (kseg_rule(K, M, flags) == 2) {
     seg_part = (float*)q;
     seg_flags = (unsigned*)(q + seg_part_bytes(T, K, M));
     zero_words_kernel<<<dim3((unsigned)(seg_flag_words(T, K, M) / 1024)), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(seg_flags));
@@ -1131,7 +1138,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
     if (rc != TE_OK) return rc;
     x_planes = Xs;
   }
-  int wm = choose_geo((M % 256 == 0) ? 2 : 1, T, M, flags & 3, 192, true, kseg_rule(K, M));
+  int wm = choose_geo((M % 256 == 0) ? 2 : 1, T, M, flags & 3, 192, true, kseg_rule(K, M, flags));
   X6Params p{};
   p.status = status;
   p.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
@@ -1221,13 +1228,13 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   const int wm_max = pick_wm(in_f, out_f);
   const int pin_z = ((flags >> TE_X6_TILE_Z_SHIFT) & 3) ? ((flags >> TE_X6_TILE_Z_SHIFT) & 3) : (flags & 3);      // per-pass pins win
   const int pin_c = ((flags >> TE_X6_TILE_C_SHIFT) & 3) ? ((flags >> TE_X6_TILE_C_SHIFT) & 3) : (flags & 3);
-  const int wm_z = choose_geo(wm_max, T, out_f, pin_z, 256, true, kseg_rule(in_f, out_f));
+  const int wm_z = choose_geo(wm_max, T, out_f, pin_z, 256, true, kseg_rule(in_f, out_f, flags));
   const int wm_c = choose_geo(wm_max, T, 2 * in_f, pin_c);
 #ifdef TE_X6_STUDY
   const int study = (flags >> 5) & 7;      // study builds: run ablation `study` of the main loop instead
   flags &= ~0xe0;
 #endif
-  if ((flags & ~(0x1f | TE_X6_STAGES_3 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(0x1f | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0) return TE_ERR_INVALID_ARG;
   const bool three_stages = (flags & TE_X6_STAGES_3) != 0;
   int wm = 0;
   X6Params p{};
@@ -1265,7 +1272,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
     p.rows_w = (int)out_f;
     p.flags = flag_words;
     p.seg_part = nullptr, p.seg_flags = nullptr;
-    if (kseg_rule(in_f, out_f) == 2) {
+    if (kseg_rule(in_f, out_f, flags) == 2) {
       p.seg_part = (float*)seg_region;
       p.seg_flags = (unsigned*)(seg_region + seg_part_bytes(T, in_f, out_f));
       zero_words_kernel<<<dim3((unsigned)(seg_flag_words(T, in_f, out_f) / 1024)), dim3(256), 0, stream>>>(
@@ -1376,7 +1383,7 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
       (bias && !te_aligned16(bias)) || (x_abs_planes && !te_aligned16(x_abs_planes)))
     return TE_ERR_UNSUPPORTED;
   if (r_scale && (rows_per_sample <= 0 || rows_per_sample > 0x7fffffff || T % rows_per_sample)) return TE_ERR_INVALID_ARG;
-  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const float beta = alpha - 1.0f;
   unsigned char* q = (unsigned char*)ws;
@@ -1417,7 +1424,7 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
   // one launch: a Z-like pass (K = in_f, weight-side rows = out_f) or an output-side pass (K = out_f)
   auto seg_setup = [&](X6Params& p, int64_t K, int64_t rows_w) {
     p.seg_part = nullptr, p.seg_flags = nullptr;
-    if (kseg_rule(K, rows_w) == 2) {
+    if (kseg_rule(K, rows_w, flags) == 2) {
       p.seg_part = (float*)seg_region;
       p.seg_flags = (unsigned*)(seg_region + seg_part_bytes(T, K, rows_w));
       zero_words_kernel<<<dim3((unsigned)(seg_flag_words(T, K, rows_w) / 1024)), dim3(256), 0, stream>>>(
@@ -1435,7 +1442,7 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
     p.rows_w = (int)out_f;
     p.flags = flag_words + (size_t)(pass++) * (kFlagBytes / 4);
     seg_setup(p, in_f, out_f);
-    const int wm = choose_geo(pick_wm(in_f, out_f), T, out_f, pin, 256, true, kseg_rule(in_f, out_f));
+    const int wm = choose_geo(pick_wm(in_f, out_f), T, out_f, pin, 256, true, kseg_rule(in_f, out_f, flags));
     return launch_x6_mode<MODE>(wm, three_stages, p, stream);
   };
   int rc;
@@ -1489,7 +1496,7 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
       p.scale = scale, p.accum = accum, p.x_sign = sign;
       p.flags = flag_words + (size_t)(pass++ % kGeneralPasses) * (kFlagBytes / 4);
       seg_setup(p, out_f, in_f);
-      const int wm = choose_geo((in_f % 256 == 0) ? 2 : 1, T, in_f, pin, 192, true, kseg_rule(out_f, in_f));
+      const int wm = choose_geo((in_f % 256 == 0) ? 2 : 1, T, in_f, pin, 192, true, kseg_rule(out_f, in_f, flags));
       return launch_x6_mode<MODE_X>(wm, three_stages, p, stream);
     };
     for (int half = 0; half < (beta != 0.0f ? 2 : 1); ++half) {
