@@ -75,6 +75,9 @@ def _resolve(args):
         args.overlap_backward = "on"
     if args.steps is None:
         args.steps = -(-SWEEP_IMAGES // SWEEP_GLOBAL_BATCH) if args.config == "sweep50k" else 5
+    args.inflight_auto = args.inflight is None       # resolved in main() once the per-GPU batch is known
+    if args.inflight is None:
+        args.inflight = 1
     return args
 
 
@@ -109,8 +112,11 @@ def parse_args(argv=None):
                          "maps, graph-capturable.  auto (default since round 3) = on (ViT-B/16: 851 vs 803 maps/s under rocprofv3, one "
                          "trip; ViT-L/16-384: 81.7 vs 79.1; BERT-512: profiles/r03_overlap_backward_ab.log); the eager probe "
                          "step that feeds the roofline block always runs serially")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="consecutive steps (batches) in flight, each on its own HIP stream (eager launches)")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="consecutive steps (batches) in flight, each replayed / launched on its own HIP stream.  Default: 2 "
+                         "where the step is a replayed HIP graph (ViT-B/16 and the sweep: 925 vs 896 maps/s, same box, A B A B, "
+                         "profiles/r04_inflight2.log), 1 for the eager configurations (a second ViT-L/16-384 step in flight would "
+                         "be another 117 GB of activations)")
     ap.add_argument("--linear", choices=["x6", "fp32"], default="x6",
                     help="Linear.relprop kernels: x6 (default) = bf16 MFMAs on three-way split fp32 operands, six partial "
                          "products, fp32 accumulation (csrc/te_linear_x6.hip; fp32-class accuracy, asserted by the parity "
@@ -585,6 +591,12 @@ def main():
 
     wl = Workload(args, rank, dev)
     B = wl.B
+    if args.inflight_auto:
+        # two replayed steps in flight where the step is a HIP graph AND a second step's activations are affordable: a ViT-B
+        # step holds ~0.38 GB per sample (24 GB at batch 64; the one-GPU sweep's batch of 256 would be 2 x 96 GB + the eager
+        # probe step's 96 GB: out of memory on a 288 GB part -- found the hard way, trip t16)
+        graph = args.graph == "on" or (args.graph == "auto" and args.config in ("vit_b16_224", "sweep50k"))
+        args.inflight = 2 if (graph and B <= 64) else 1
     log(f"rank {rank}/{world}: {wl.title} model + {B} inputs resident on {dev}")
 
     timer = KernelTimer()
@@ -593,9 +605,10 @@ def main():
 
     # --inflight N: round 3 refused it (two step graphs in flight "hung": every expired hand-over wait of the x6 kernels cost
     # seconds, and they expired one after the other).  Since round 4 the waits are bounded at 250 ms, fail fast once one has
-    # expired and end in a TeError below, so the option is safe to use; measured on the MI355X it is worth +1.6 % with two
-    # steps in flight and nothing with three (profiles/r04_inflight2.log) -- relprop beside the backward pass already fills
-    # most of the gaps -- so the default stays one step in flight.
+    # expired and end in a TeError below (a workgroup only ever waits for a LOWER-numbered workgroup of its own launch, whose
+    # publishing fragment is the first thing that one runs, so concurrent launches cannot starve each other).  Two replayed
+    # steps in flight let the forward pass of step k + 1 run beside the relprop tail of step k: +3.2 % (923.7 / 926.7 vs
+    # 896.0 / 896.5 maps/s, same box, A B A B); three: nothing more.
     lanes = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
 
@@ -625,29 +638,23 @@ def main():
 
     def step(eager=False, k=None):
         inputs = wl.inputs if not wl.sweep else (wl.sweep_inputs[(args.warmup + k) if k is not None else 0],)
-        if graphed is not None and not eager:
-            out = graphed(*inputs)
-        elif eager:
-            join()                       # the probe step runs alone: its kernel durations must be its own
-            out = wl.eager_serial(*inputs)
-        elif lanes is None:
-            out = wl.eager(*inputs)
-        else:
-            out = None
-        if out is not None:
+
+        def keep(out):        # the sweep keeps every step's maps (a graph's static output is overwritten by its next replay)
             if wl.sweep and k is not None:
-                sweep_maps[k].copy_(out)         # (the graph's static output is overwritten by the next replay)
+                sweep_maps[k].copy_(out)
             return out
-        inputs = wl.inputs
-        # every tensor of a step is allocated, produced and consumed on that step's stream
+        if eager:
+            join()                       # the probe step runs alone: its kernel durations must be its own
+            return keep(wl.eager_serial(*inputs))
+        if lanes is None:
+            return keep(graphed(*inputs) if graphed is not None else wl.eager(*inputs))
+        # several steps in flight: every tensor of a step is allocated, produced and consumed on that step's stream
         i = counter[0] % len(lanes)
         lane = lanes[i]
         counter[0] += 1
         lane.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(lane):
-            if lane_graphs is not None:
-                return lane_graphs[i](*wl.inputs)
-            return wl.eager(*wl.inputs)
+            return keep(lane_graphs[i](*inputs) if lane_graphs is not None else wl.eager(*inputs))
 
     def join():
         if lanes is not None:
@@ -658,7 +665,7 @@ def main():
         maps = step()
         torch.cuda.synchronize()
         log(f"warmup step {w_} done")
-    if graphed is not None and not args.no_roofline and args.warmup > 0:
+    if (graphed is not None or lane_graphs is not None) and not args.no_roofline and args.warmup > 0:
         # The probe step of the timed region runs EAGERLY; capture emptied the caching allocator (GraphedCall), so its ~1000
         # allocations would each be a fresh hipMalloc inside the timed region (measured: 100-350 ms of host time for one
         # step, launches stalled for up to 17 ms between their two events).  One untimed eager step leaves the blocks in
@@ -712,14 +719,31 @@ def main():
         try:
             g2 = None
             if used_graph:
-                graphed = None      # release the first graph's private memory pool before capturing the second
-                g2 = GraphedCall(wl.eager, wl.inputs)
-            run2 = (lambda: g2(*wl.inputs)) if g2 is not None else (lambda: wl.eager(*wl.inputs))
-            run2()
+                graphed = None      # release the first graphs' private memory pools before capturing the comparison's
+                g2 = [GraphedCall(wl.eager, wl.inputs) for _ in range(max(1, args.inflight))]
+            lanes2 = [torch.cuda.Stream(device=dev) for _ in range(len(g2))] if g2 is not None and len(g2) > 1 else None
+
+            def run2(i):
+                if g2 is None:
+                    return wl.eager(*wl.inputs)
+                if lanes2 is None:
+                    return g2[0](*wl.inputs)
+                lane2 = lanes2[i % len(lanes2)]
+                lane2.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(lane2):
+                    return g2[i % len(g2)](*wl.inputs)
+
+            def join2():
+                for l2 in lanes2 or ():
+                    torch.cuda.current_stream(dev).wait_stream(l2)
+            for i2 in range(len(g2) if g2 is not None else 1):
+                run2(i2)
+            join2()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                m2 = run2()
+            for i2 in range(args.steps):
+                m2 = run2(i2)
+            join2()
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t1
             assert torch.isfinite(m2).all()
@@ -727,8 +751,8 @@ def main():
             fp32_cmp = {"fp32_mfma_maps_per_s" if wl.noun == "maps" else "fp32_mfma_sequences_per_s": B * args.steps / e2,
                         "fp32_mfma_ms_per_step": e2 / args.steps * 1e3,
                         "fp32_mfma_note": "the same step with the Linear rules on the fp32-MFMA kernels (te_linear.hip) and the "
-                                          "layers' own products on the stock fp32 GEMMs (no bf16 MFMA anywhere), one "
-                                          "graph replayed step after step; second timed run of this process"}
+                                          "layers' own products on the stock fp32 GEMMs (no bf16 MFMA anywhere), replayed "
+                                          "with the same number of steps in flight; second timed run of this process"}
             log(f"fp32-MFMA comparison run: {e2 / args.steps * 1e3:.2f} ms/step")
             del g2
         finally:

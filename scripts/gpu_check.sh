@@ -18,7 +18,7 @@ prof() {   # prof <outdir> <bench args...>: rocprofv3 kernel stats of one bench 
   rm -f gpurun_out/$out/*agent_info* gpurun_out/$out/*kernel_trace*
 }
 prof prof --steps 10
-prof prof_serial --steps 10 --overlap-backward off
+prof prof_serial --steps 10 --overlap-backward off --inflight 1
 ( timeout 400 bash scripts/x6_pmc.sh > gpurun_out/x6_pmc.log 2>&1 )
 for cfg in vit_l16_384 bert_base_512; do
   ( timeout 300 python bench.py --config $cfg --steps 3 --warmup 1 --cpu-maps 2 > gpurun_out/bench_$cfg.json 2> gpurun_out/bench_$cfg.err )
