@@ -1,5 +1,16 @@
-import sys, os, time, copy
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests/golden')
+"""CPU probe: can a synthetic ViT-B/16 be initialised so that the REFERENCE reproduces its own
+transformer_attribution map to 1e-4 (min-max normalised) under rounding-level noise?  Runs the reference's generate_LRP on
+three images per variant with 6 draws of make_golden._RoundingNoise.  Result: profiles/r04_conditioning_probe_cpu.log (no).
+
+    python scripts/conditioning_probe.py [default qk.3v.5s1 v2 s3 s3v2]      (needs the reference checkout or its stage)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch, numpy as np
 import make_golden as G
 from oracle import ref_harness as rh
