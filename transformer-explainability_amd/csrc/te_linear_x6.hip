@@ -39,6 +39,14 @@
 //   plain GEMM      MODE_G: out = X W^T + b on the same loop (te_gemm_x6_f32: the Linear layers' own forward product and
 //                   input gradient); te_linear_x6_split_dual_f32 writes the planes of a layer input and
 //                   of its absolute value in one pass, so the rule reuses what the forward product split.
+// Round 4:
+//   geometries      WM = 2 / 1 / 0: 256 x 256, 128 x 256 and 128 x 128 tiles (X6Geo); the last for launches with few weight rows
+//   other rules     variant lrp (layers_lrp.py:188-211) and alpha != 1 (layers_ours.py:225-228) as further epilogue modes of
+//                   the same loop: MODE_ZI, MODE_Z1, MODE_CI, MODE_X (te_linear_relprop_x6_general_f32)
+//   loud hand-over  a wait for another workgroup's accumulators is bounded (250 ms), sets a sticky status word, poisons the
+//                   tile with NaN and makes every later wait give up at once: never a plausible wrong result, never a hang
+//   main loop       raw s_barrier + counted s_waitcnt (a __syncthreads() drains direct-to-LDS loads); NST = 3 (prefetch
+//                   distance 2) and KSPLIT = 2 (two K segments per output) are measured studies, off by default
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
