@@ -60,7 +60,8 @@ def main():
 
             def gemm():
                 _lib.check(lib.te_gemm_x6_f32(X.data_ptr(), xp.data_ptr(), wp.data_ptr(), b_ptr, out.data_ptr(), T, K, M,
-                                              ws.data_ptr(), ws.numel(), s), "gemm")
+                                              ops.X6_TILE | ops.X6_FLAGS, ops.x6_status(dev).data_ptr(), ws.data_ptr(), ws.numel(),
+                                              s), "gemm")
 
             Wt = W if direction == "forward" else W.t().contiguous()
 

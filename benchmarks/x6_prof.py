@@ -39,7 +39,8 @@ for (lname, in_f, out_f) in shapes:
             for phase in (4, 8, 16):
                 _lib.check(lib.te_linear_relprop_x6_f32(R.data_ptr(), None, 0, 1, X.data_ptr(), W.data_ptr(), planes.data_ptr(),
                                                         None, Y.data_ptr(), b.data_ptr(), out.data_ptr(), T, in_f, out_f,
-                                                        a.tile | phase | (study << 5), ws.data_ptr(), ws.numel(), st), "x6")
+                                                        a.tile | phase | (study << 5), ops.x6_status(dev).data_ptr(), ws.data_ptr(),
+                                                        ws.numel(), st), "x6")
         torch.cuda.synchronize()
         for pi, pname in enumerate(("zpass", "cpass")):
             raw = ws[off_flags + pi * 65536 + 8192: off_flags + pi * 65536 + 8192 + 512 * 64].view(torch.int64).view(512, 8).cpu()
