@@ -132,8 +132,10 @@ def parse_args(argv=None):
                          "(baselines/ViT/ViT_LRP.py, method transformer_attribution: the headline), lrp = modules/layers_lrp.py "
                          "(baselines/ViT/ViT_orig_LRP.py, method grad: separate denominators per sign, 4 instead of 3 products per "
                          "Linear rule -- te_linear_relprop_x6_general_f32)")
-    ap.add_argument("--x6-tile", choices=["auto", "128", "256"], default="auto",
-                    help="tile geometry of the x6 Linear kernels (measurement knob: the maps do not depend on it)")
+    ap.add_argument("--x6-tile", choices=["auto", "lib", "128", "256"], default="auto",
+                    help="tile geometry of the x6 Linear kernels (the maps do not depend on it, bit for bit): auto = 256 x 256 "
+                         "tiles wherever the feature counts allow while the step runs concurrent streams (least CU-time per "
+                         "launch), else the library's per-launch policy; lib = that policy always; 128 / 256 = pinned")
     ap.add_argument("--producers", choices=["stock", "fused"], default="fused",
                     help="fused (default): the attention blocks' forward and attention-gradient backward run on the "
                          "hand-written producer kernels (SURVEY.md 8f.1: head dim 64; N <= 224 one workgroup per head, N <= 640 "
@@ -587,7 +589,14 @@ def main():
         ops.USE_FUSED_PRODUCERS = True
     ops.X6_GEMM = args.x6_gemm
     ops.USE_LINEAR_X6 = args.linear == "x6"
-    ops.X6_TILE = {"auto": 0, "128": 1, "256": 2}[args.x6_tile]
+    # x6 tile geometry.  The library's own policy (TE_X6_TILE_AUTO) optimises a launch running ALONE (few weight rows ->
+    # smaller tiles so that every CU gets work).  A step, however, keeps several streams busy (relprop beside the backward
+    # pass, two steps in flight): the CUs a narrow launch leaves idle are used by the other streams' kernels, and what counts
+    # is CU-time per launch -- 150 workgroups of 256 x 256 tiles on 150 CUs cost 56 k CU-us where 128 x 128 tiles on all 256
+    # cost 92 k (fc2's forward).  Measured, same box, A B A B, two steps in flight: 948 vs 928 maps/s
+    # (profiles/r04_x6_geometry_step_ab.log).  So "auto" pins the large tiles whenever the step runs concurrent streams.
+    concurrent = args.overlap_backward == "on" or args.inflight > 1 or args.inflight_auto
+    ops.X6_TILE = {"auto": 2 if concurrent else 0, "lib": 0, "128": 1, "256": 2}[args.x6_tile]
 
     wl = Workload(args, rank, dev)
     B = wl.B
