@@ -295,6 +295,9 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
 #define TE_X6_KSPLIT 0x8000            /* study, off by default: products with K >= 1536 and <= 768 weight rows as two K segments per
                                           output (two k-ordered chains, summed once).  It changes the bits: set it for every
                                           launch of a process or for none.  Measured: no gain in the step */
+#define TE_X6_WHOLE_TILES 0x10000       /* ranges cut at tile boundaries only, whatever the fill of the last round: for callers that
+                                          keep several streams busy (the idle CUs of a last round are used by their other kernels,
+                                          and no tile is handed over between workgroups).  Same results, bit for bit */
 #define TE_X6_TEST_SMALL_GRID 0x4000   /* tests: a persistent grid of 16 workgroups, so that small shapes get stream-K cuts */
 #define TE_X6_TILE_Z_SHIFT 10
 #define TE_X6_TILE_C_SHIFT 12

@@ -255,7 +255,7 @@ def test_linear_x6_schedules_are_bitwise_equal(T, in_f, out_f):
         gbase = ops.gemm_x6(Xd, wp, bd, out_f)
         check(f"gemm_x6_small({T},{in_f},{out_f})", gbase, Y, 1e-5)
         for tile in (1, 2, 3):                   # 128 x 256, 256 x 256, 128 x 128 tiles
-            for st in (0, ops.TE_X6_STAGES_3):
+            for st in (0, ops.TE_X6_STAGES_3, ops.TE_X6_WHOLE_TILES):      # (+ ranges cut at tile boundaries only)
                 for grid in (0, ops.TE_X6_TEST_SMALL_GRID):
                     ops.X6_TILE, ops.X6_FLAGS = tile, st | grid
                     got = ops.linear_relprop(Rd, Xd, Wd, Y=Y, bias=bd, cache=cache)

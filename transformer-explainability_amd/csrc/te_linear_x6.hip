@@ -233,6 +233,7 @@ struct X6Params {
   long long spin_ticks;        // wall_clock64 ticks a workgroup waits for a predecessor before it gives up
   int drop_handover;           // TE_X6_TEST_DROP_HANDOVER: publishers keep their flag down (tests: a wait must expire)
   int small_grid;              // TE_X6_TEST_SMALL_GRID: 16 workgroups (tests: stream-K cuts on small shapes)
+  int prefer_whole;            // TE_X6_WHOLE_TILES: cut the ranges at tile boundaries whatever the fill of the last round
   // Z-pass epilogue
   const float* R;
   const float* Y;
@@ -981,7 +982,10 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
   // profiles/r03_x6_whole_tiles.log) -- which pays as long as the last round is nearly full.  r = tiles per workgroup;
   // whole tiles cost ceil(r) rounds.  Either way every output is the same k-ordered chain: results do not change.
   const double r = (double)tiles / (8.0 * spx);
-  if (!q.whole_tiles_forced) q.whole_tiles = (std::ceil(r) <= kWholeTileSlack * r && !p.small_grid) ? 1 : 0;
+  // TE_X6_WHOLE_TILES (the caller runs concurrent streams): whole tiles always -- the last round's idle CUs are not lost, the
+  // other streams' kernels use them, while stream-K keeps ALL CUs for the whole launch at the slower skewed step
+  if (!q.whole_tiles_forced)
+    q.whole_tiles = ((p.prefer_whole || std::ceil(r) <= kWholeTileSlack * r) && !p.small_grid) ? 1 : 0;
   if (!q.status) q.status = q.flags + kErrWord;
   q.spin_ticks = spin_ticks_for_current_device();
   kern<<<dim3(8 * spx), dim3(GEO::THREADS), lds, stream>>>(q);
@@ -1119,7 +1123,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
                               int64_t T, int64_t K, int64_t M, int flags, unsigned* status, void* ws, size_t ws_bytes,
                               te_stream_t stream_) {
   if ((!X && !x_planes) || !w_planes || !out) return TE_ERR_INVALID_ARG;
-  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_WHOLE_TILES | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
   if (!te_gemm_x6_supported(T, K, M)) return TE_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < te_gemm_x6_workspace_bytes(T, K, M) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
   if ((X && !te_aligned16(X)) || !te_aligned16(out) || !te_aligned16(w_planes) || (bias && !te_aligned16(bias)) ||
@@ -1151,6 +1155,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
   p.status = status;
   p.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
   p.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
+  p.prefer_whole = (flags & TE_X6_WHOLE_TILES) ? 1 : 0;
 #ifdef TE_X6_STUDY
   if (const char* e = getenv("TE_X6_ORDER")) p.t_fast = atoi(e);
   if (const char* e = getenv("TE_X6_SNAP")) p.whole_tiles = atoi(e), p.whole_tiles_forced = 1;
@@ -1242,7 +1247,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   const int study = (flags >> 5) & 7;      // study builds: run ablation `study` of the main loop instead
   flags &= ~0xe0;
 #endif
-  if ((flags & ~(0x1f | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(0x1f | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_WHOLE_TILES | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0) return TE_ERR_INVALID_ARG;
   const bool three_stages = (flags & TE_X6_STAGES_3) != 0;
   int wm = 0;
   X6Params p{};
@@ -1269,6 +1274,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   p.status = status;
   p.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
   p.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
+  p.prefer_whole = (flags & TE_X6_WHOLE_TILES) ? 1 : 0;
   int rc;
   if (phases & TE_X6_PHASE_Z) {   // Z-pass: D[j][t] = sum_k |W|[j][k] |X|[t][k]
     p.A = wz;
@@ -1391,7 +1397,7 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
       (bias && !te_aligned16(bias)) || (x_abs_planes && !te_aligned16(x_abs_planes)))
     return TE_ERR_UNSUPPORTED;
   if (r_scale && (rows_per_sample <= 0 || rows_per_sample > 0x7fffffff || T % rows_per_sample)) return TE_ERR_INVALID_ARG;
-  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
+  if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_WHOLE_TILES | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const float beta = alpha - 1.0f;
   unsigned char* q = (unsigned char*)ws;
@@ -1426,6 +1432,7 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
   base.status = status;
   base.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
   base.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
+  base.prefer_whole = (flags & TE_X6_WHOLE_TILES) ? 1 : 0;
   const bool three_stages = (flags & TE_X6_STAGES_3) != 0;
   const int pin = flags & 3;
   int pass = 0;

@@ -122,6 +122,7 @@ X6_TILE = 0          # te_relprop.h TE_X6_TILE_*: 0 auto, 1 = 128-row weight til
 X6_FLAGS = int(os.environ.get("TE_X6_FLAGS", "0"), 0)   # extra te_relprop.h flag bits for every x6 launch (TE_X6_STAGES_3, per-pass tile pins, test hooks)
 TE_X6_PHASE_SPLIT, TE_X6_PHASE_Z, TE_X6_PHASE_C = 4, 8, 16
 TE_X6_STAGES_3, TE_X6_TEST_DROP_HANDOVER, TE_X6_TILE_Z_SHIFT, TE_X6_TILE_C_SHIFT, TE_X6_TEST_SMALL_GRID = 0x100, 0x200, 10, 12, 0x4000
+TE_X6_WHOLE_TILES = 0x10000     # whole-tile ranges always (callers that keep several streams busy); same bits
 TE_X6_KSPLIT = 0x8000      # study (off): two K segments per output for long-K / narrow-output products; changes the bits
 
 # A workgroup of an x6 kernel that continues a tile another workgroup started waits for that one's accumulators; the wait
