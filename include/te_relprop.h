@@ -53,6 +53,10 @@ int te_version(void);
 const char* te_status_string(int status);
 /* 0 if device 0..n-1 contains a gfx950 agent usable by this library, TE_ERR_NO_DEVICE otherwise */
 int te_device_check(void);
+/* 1 if the library was built with -DTE_X6_STUDY (measurement builds: TE_X6_STAGES_3 / TE_X6_KSPLIT schedules and the
+ * main-loop ablations are compiled in), 0 for the shipped library, whose x6 entry points answer TE_ERR_UNSUPPORTED to
+ * those flags. */
+int te_x6_study_build(void);
 
 /* ---- a3  Linear.relprop -------------------------------------------------------------------
  * replaces modules/layers_ours.py:207-230 (ours) and modules/layers_lrp.py:188-211 (lrp), and the
@@ -276,7 +280,9 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
  * a tile, else 128 rows / two 256-thread workgroups per CU; the result does not depend on the tile geometry, bit for
  * bit), TE_X6_TILE_128 / TE_X6_TILE_256 pin it; shifted left by TE_X6_TILE_Z_SHIFT / TE_X6_TILE_C_SHIFT they pin one pass.
  * TE_X6_TILE_128x128: 128 x 128 tiles, three 256-thread workgroups per CU (launches with few weight rows).
- * TE_X6_STAGES_3: three LDS stages instead of two in the 256-row geometry (measurement; same results).
+ * TE_X6_STAGES_3: three LDS stages instead of two in the 256-row geometry (measurement; same results).  STUDY BUILDS ONLY
+ * (-DTE_X6_STUDY, te_x6_study_build() == 1): the shipped library does not contain the instantiation and answers
+ * TE_ERR_UNSUPPORTED -- likewise TE_X6_KSPLIT.
  *
  * Failure is loud.  A workgroup that continues a tile another workgroup started waits for that one's accumulators for at
  * most 250 ms.  If the wait expires it ORs 1 into *status -- a caller-owned, caller-zeroed device word that is NEVER

@@ -36,7 +36,7 @@ def test_binding_covers_header():
 
 
 def test_version_and_status(lib):
-    assert lib.te_version() >= 400
+    assert lib.te_version() >= 500
     assert lib.te_status_string(0) == b"ok"
     assert b"workspace" in lib.te_status_string(-2)
 

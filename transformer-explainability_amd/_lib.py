@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TE_RELPROP_LIB") or os.path.join(_PKG, "lib", "libte_relprop.so")
 
 TE_OK = 0
-MIN_LIB_VERSION = 400      # te_version(): 0.4.0, the round-4 ABI (x6 entry points take flags + a status word)
+MIN_LIB_VERSION = 500      # te_version(): 0.5.0, the round-5 ABI
 TE_ERR_UNSUPPORTED = -3
 TE_VARIANT_OURS = 0
 TE_VARIANT_LRP = 1
@@ -33,6 +33,7 @@ SIGNATURES = {
     "te_version": (_I, []),
     "te_status_string": (c_char_p, [_I]),
     "te_device_check": (_I, []),
+    "te_x6_study_build": (_I, []),
     "te_linear_relprop_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
     "te_linear_relprop_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_linear_zpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),

@@ -3,7 +3,15 @@
 
 #include <string.h>
 
-extern "C" int te_version(void) { return 400; /* 0.4.0: round 4 -- x6 entry points take flags + a status word; the general rule */ }
+extern "C" int te_version(void) { return 500; /* 0.5.0: round 5 -- study schedules out of the shipped build (te_x6_study_build) */ }
+
+extern "C" int te_x6_study_build(void) {
+#ifdef TE_X6_STUDY
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 extern "C" const char* te_status_string(int status) {
   switch (status) {

@@ -925,7 +925,21 @@ inline size_t planes_bytes(int64_t rows, int64_t K) {
 // sequences/s: at T = 16 384 the un-split 128 x 128 launch is exactly one tile per workgroup slot) -- the CUs a narrow
 // launch leaves idle are used by the other stream of the step anyway.  Not shipped.
 inline int kseg_shape(int64_t K, int64_t rows_w) { return (K >= 1536 && rows_w <= 768 && (K / 16) % 2 == 0) ? 2 : 1; }
+#ifdef TE_X6_STUDY
 inline int kseg_rule(int64_t K, int64_t rows_w, int flags) { return (flags & TE_X6_KSPLIT) ? kseg_shape(K, rows_w) : 1; }
+#else
+inline int kseg_rule(int64_t, int64_t, int) { return 1; }
+#endif
+// study-only schedules (TE_X6_STAGES_3, TE_X6_KSPLIT) are not compiled into the shipped library: a caller that asks for one
+// gets TE_ERR_UNSUPPORTED instead of a heavily spilling kernel
+inline bool study_flags_refused(int flags) {
+#ifdef TE_X6_STUDY
+  (void)flags;
+  return false;
+#else
+  return (flags & (TE_X6_STAGES_3 | TE_X6_KSPLIT)) != 0;
+#endif
+}
 inline size_t seg_part_bytes(int64_t T, int64_t K, int64_t rows_w) {       // accumulators of segment 0, any geometry
   return kseg_shape(K, rows_w) == 2 ? te_align_up((size_t)te_ceil_div(T, 256) * 256 * (size_t)rows_w * 4, 256) : 0;
 }
@@ -998,6 +1012,7 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
 // traffic in flight costs more than its latency cover buys.
 template <int MODE>
 int launch_x6_mode(int wm, bool three_stages, const X6Params& p, hipStream_t stream) {
+#ifdef TE_X6_STUDY      // NST = 3 and KSPLIT = 2 are measured studies: compiled into study builds only
   if constexpr (MODE != MODE_C && MODE != MODE_CI) {
     if (p.seg_part && p.seg_flags && kseg_shape((int64_t)p.nks * 16, p.rows_w) == 2) {
       if (wm == 2) return launch_x6<2, MODE, 0, 2, 2>(p, stream);
@@ -1005,7 +1020,11 @@ int launch_x6_mode(int wm, bool three_stages, const X6Params& p, hipStream_t str
       return launch_x6<0, MODE, 0, 2, 2>(p, stream);
     }
   }
-  if (wm == 2) return three_stages ? launch_x6<2, MODE, 0, 3>(p, stream) : launch_x6<2, MODE, 0, 2>(p, stream);
+  if (wm == 2 && three_stages) return launch_x6<2, MODE, 0, 3>(p, stream);
+#else
+  if (three_stages || p.seg_part || p.seg_flags) return TE_ERR_UNSUPPORTED;      // (the entry points reject the flags first)
+#endif
+  if (wm == 2) return launch_x6<2, MODE, 0, 2>(p, stream);
   if (wm == 1) return launch_x6<1, MODE, 0, 2>(p, stream);
   return launch_x6<0, MODE, 0, 2>(p, stream);
 }
@@ -1124,6 +1143,7 @@ extern "C" int te_gemm_x6_f32(const float* X, const void* x_planes, const void* 
                               te_stream_t stream_) {
   if ((!X && !x_planes) || !w_planes || !out) return TE_ERR_INVALID_ARG;
   if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_WHOLE_TILES | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
+  if (study_flags_refused(flags)) return TE_ERR_UNSUPPORTED;
   if (!te_gemm_x6_supported(T, K, M)) return TE_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < te_gemm_x6_workspace_bytes(T, K, M) || !te_aligned16(ws)) return TE_ERR_WORKSPACE;
   if ((X && !te_aligned16(X)) || !te_aligned16(out) || !te_aligned16(w_planes) || (bias && !te_aligned16(bias)) ||
@@ -1248,6 +1268,7 @@ extern "C" int te_linear_relprop_x6_f32(const float* R, const float* r_scale, in
   flags &= ~0xe0;
 #endif
   if ((flags & ~(0x1f | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_WHOLE_TILES | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID | 0x3c00)) != 0) return TE_ERR_INVALID_ARG;
+  if (study_flags_refused(flags)) return TE_ERR_UNSUPPORTED;
   const bool three_stages = (flags & TE_X6_STAGES_3) != 0;
   int wm = 0;
   X6Params p{};
@@ -1398,6 +1419,7 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
     return TE_ERR_UNSUPPORTED;
   if (r_scale && (rows_per_sample <= 0 || rows_per_sample > 0x7fffffff || T % rows_per_sample)) return TE_ERR_INVALID_ARG;
   if ((flags & ~(3 | TE_X6_STAGES_3 | TE_X6_KSPLIT | TE_X6_WHOLE_TILES | TE_X6_TEST_DROP_HANDOVER | TE_X6_TEST_SMALL_GRID)) != 0) return TE_ERR_INVALID_ARG;
+  if (study_flags_refused(flags)) return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   const float beta = alpha - 1.0f;
   unsigned char* q = (unsigned char*)ws;
@@ -1429,7 +1451,10 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
   base.rs_stride = r_scale_stride;
   base.rps = (int)(r_scale ? rows_per_sample : 1);
   base.out = out;
-  base.status = status;
+  // status = NULL: ONE per-call error word for all launches of the rule, in the last flag region -- which no launch uses (at
+  // most four passes per half) and which the reset between the two halves of variant lrp leaves alone, so a failure of the
+  // first half is not lost
+  base.status = status ? status : flag_words + (size_t)(kGeneralPasses - 1) * (kFlagBytes / 4) + kErrWord;
   base.drop_handover = (flags & TE_X6_TEST_DROP_HANDOVER) ? 1 : 0;
   base.small_grid = (flags & TE_X6_TEST_SMALL_GRID) ? 1 : 0;
   base.prefer_whole = (flags & TE_X6_WHOLE_TILES) ? 1 : 0;
@@ -1520,7 +1545,8 @@ extern "C" int te_linear_relprop_x6_general_f32(const float* R, const float* r_s
       const float sc = half ? -beta : alpha;
       if (half) {       // the second half reuses the flag regions of the first: reset them (stream-ordered after their use)
         pass = 0;
-        zero_words_kernel<<<dim3(kGeneralPasses * kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
+        static_assert(kGeneralPasses >= 5, "four passes per half + the region of the per-call error word");
+        zero_words_kernel<<<dim3(4 * kFlagBytes / 16 / 256), dim3(256), 0, stream>>>(reinterpret_cast<u32x4*>(flag_words));
       }
       rc = z_like(std::integral_constant<int, MODE_Z1>{}, w1, Xa, Sa);
       if (rc != TE_OK) return rc;

@@ -75,7 +75,14 @@ class LRP:
         self.prune = bool(prune)
 
     def generate_LRP(self, input, index=None, method="transformer_attribution", is_ablation=False, start_layer=0):
-        return self._generate(input, index, method, is_ablation, start_layer)
+        # a lost x6 hand-over of an EARLIER call is raised here, once, without synchronising (ops.x6_poll); NaN in a map
+        # means exactly that -- check() asks about the calls made so far (and synchronises)
+        if input.is_cuda:
+            ops.x6_poll(input.device)
+        out = self._generate(input, index, method, is_ablation, start_layer)
+        if input.is_cuda:
+            ops.x6_post(input.device)
+        return out
 
     def check(self):
         """Raise TeError if any x6 Linear kernel since the last check lost a stream-K hand-over (the affected maps carry
@@ -327,8 +334,13 @@ class Generator:
         return layers
 
     def generate_LRP(self, input_ids, attention_mask, index=None, start_layer=11):
+        if input_ids.is_cuda:
+            ops.x6_poll(input_ids.device)        # a lost x6 hand-over of an earlier call: raised once, no synchronisation
         self._explain(input_ids, attention_mask, index, lowest_layer=start_layer)
-        return self.attribution_tail(start_layer)
+        out = self.attribution_tail(start_layer)
+        if input_ids.is_cuda:
+            ops.x6_post(input_ids.device)
+        return out
 
     def attribution_tail(self, start_layer=11):
         """ExplanationGenerator.py:47-59 on the attn_cam / attention gradients cached by relprop + backward."""

@@ -200,9 +200,11 @@ class SaliencySweep:
         for data, target in loader_batches:
             dev = self.device if self.device is not None else data.device
             vis = self.explain(normalize(data.to(dev)), target.to(dev))
-            store.append(data, target, vis)       # (copies to the host: the device is synchronised here anyway)
             if torch.is_tensor(vis) and vis.is_cuda:
-                ops.x6_raise_if_failed(vis.device)    # never store maps of a step whose x6 hand-over failed
+                # never store maps of a step whose x6 hand-over failed: check BEFORE the append (it synchronises, which
+                # the store's host copy would do anyway), so a failed batch is neither written nor counted
+                ops.x6_raise_if_failed(vis.device)
+            store.append(data, target, vis)
         return store
 
 
