@@ -347,18 +347,31 @@ class Workload:
             self.cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
             self.start_layer = 1 if args.start_layer is None else args.start_layer
             if self.sweep:
-                # rank r owns the contiguous block [r K B, (r + 1) K B) of the K * world * B images (parallel.sweep_layout);
-                # step k explains its k-th batch.  All inputs resident in HBM before the timed region (600 KB per image).
+                # The layout the CPU tests validate (parallel.sweep_layout): rank r owns the contiguous block r of the
+                # 50 000 GLOBAL indices and walks it in batches of 256 / world -- 195 whole batches and one short one (80
+                # images on one rank, 10 per rank on eight); --steps k < 196 runs the first k batches of every rank's block.
+                # --batch pins a per-rank batch instead (a rank's share measured on fewer GPUs): whole batches only.
+                # All inputs resident in HBM before the timed region (600 KB per image).
                 from transformer_explainability_amd import parallel as par
-                K = args.steps + args.warmup
-                self.sweep_inputs = torch.empty((K, B, 3, side, side), dtype=torch.float32, device=dev)
-                lo = rank * args.steps * B
-                for k in range(K):                           # (warm-up batches recycle the first indices)
-                    for j in range(B):
-                        gi = lo + (k - args.warmup) % max(1, args.steps) * B + j
-                        self.sweep_inputs[k, j] = par.synthetic_image_on(gi, dev, (3, side, side))
-                self.inputs = (self.sweep_inputs[0],)
+                world = int(os.environ.get("WORLD_SIZE", "1"))
+                if args.batch:
+                    lo = rank * args.steps * B
+                    batches = [(lo + k * B, lo + (k + 1) * B) for k in range(args.steps)]
+                else:
+                    lo, _, bl = par.sweep_layout(SWEEP_IMAGES, world, SWEEP_GLOBAL_BATCH)[rank]
+                    if args.steps > len(bl):
+                        sys.exit(f"--config sweep50k: {args.steps} steps, but the sweep is {len(bl)} batches per rank")
+                    batches = bl[:args.steps]
+                self.sweep_batches = batches
+                self.sweep_inputs = []
+                for b_lo, b_hi in batches:
+                    x = torch.empty((b_hi - b_lo, 3, side, side), dtype=torch.float32, device=dev)
+                    for j, gi in enumerate(range(b_lo, b_hi)):
+                        x[j] = par.synthetic_image_on(gi, dev, (3, side, side))
+                    self.sweep_inputs.append(x)
+                self.inputs = (self.sweep_inputs[0],)             # (warm-up steps and graph capture: the first batch)
                 self.sweep_lo = lo
+                self.sweep_local = sum(hi_ - lo_ for lo_, hi_ in batches)
             else:
                 self.inputs = (torch.stack([synthetic_image(rank * B + i, (3, side, side)) for i in range(B)]).to(dev),)
             self.model = model.to(dev)
@@ -595,8 +608,7 @@ def main():
     # is CU-time per launch -- 150 workgroups of 256 x 256 tiles on 150 CUs cost 56 k CU-us where 128 x 128 tiles on all 256
     # cost 92 k (fc2's forward).  Measured, same box, A B A B, two steps in flight: 948 vs 928 maps/s
     # (profiles/r04_x6_geometry_step_ab.log).  So "auto" pins the large tiles whenever the step runs concurrent streams.
-    concurrent = args.overlap_backward == "on" or args.inflight > 1 or args.inflight_auto
-    ops.X6_TILE = {"auto": 2 if concurrent else 0, "lib": 0, "128": 1, "256": 2}[args.x6_tile]
+    # (resolved below, once --inflight auto is known: ADVICE r4)
 
     wl = Workload(args, rank, dev)
     B = wl.B
@@ -606,7 +618,10 @@ def main():
         # probe step's 96 GB: out of memory on a 288 GB part -- found the hard way, trip t16)
         graph = args.graph == "on" or (args.graph == "auto" and args.config in ("vit_b16_224", "sweep50k"))
         args.inflight = 2 if (graph and B <= 64) else 1
-    log(f"rank {rank}/{world}: {wl.title} model + {B} inputs resident on {dev}")
+    concurrent = args.overlap_backward == "on" or args.inflight > 1       # from the RESOLVED number of steps in flight
+    ops.X6_TILE = {"auto": 2 if concurrent else 0, "lib": 0, "128": 1, "256": 2}[args.x6_tile]
+    log(f"rank {rank}/{world}: {wl.title} model + {B} inputs resident on {dev}; x6 tile pin {ops.X6_TILE} "
+        f"({'concurrent streams' if concurrent else 'single stream'}), {args.inflight} step(s) in flight")
 
     timer = KernelTimer()
     if not args.no_roofline:
@@ -643,18 +658,22 @@ def main():
         assert (r, w) == (rank, world), (r, w, rank, world)
         log(f"rank {rank}: process group up ({torch.distributed.get_backend()})")
 
-    sweep_maps = (torch.empty((args.steps, B, wl.out_cols), dtype=torch.float32, device=dev) if wl.sweep else None)
+    sweep_maps = (torch.empty((wl.sweep_local, wl.out_cols), dtype=torch.float32, device=dev) if wl.sweep else None)
+    sweep_off = ([b_lo - wl.sweep_batches[0][0] for b_lo, _ in wl.sweep_batches] if wl.sweep else None)
 
     def step(eager=False, k=None):
-        inputs = wl.inputs if not wl.sweep else (wl.sweep_inputs[(args.warmup + k) if k is not None else 0],)
+        inputs = wl.inputs if not wl.sweep else (wl.sweep_inputs[k if k is not None else 0],)
 
         def keep(out):        # the sweep keeps every step's maps (a graph's static output is overwritten by its next replay)
             if wl.sweep and k is not None:
-                sweep_maps[k].copy_(out)
+                sweep_maps[sweep_off[k]: sweep_off[k] + out.shape[0]].copy_(out)
             return out
         if eager:
             join()                       # the probe step runs alone: its kernel durations must be its own
             return keep(wl.eager_serial(*inputs))
+        if wl.sweep and inputs[0].shape[0] != B:
+            join()                       # the short last batch of the sweep: not the captured shape -- eager launches
+            return keep(wl.eager(*inputs))
         if lanes is None:
             return keep(graphed(*inputs) if graphed is not None else wl.eager(*inputs))
         # several steps in flight: every tensor of a step is allocated, produced and consumed on that step's stream
@@ -686,18 +705,23 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    # the probe step = the last step with a whole batch (the sweep's short last batch is not what a roofline row describes)
+    probe_k = args.steps - 1
+    if wl.sweep and args.steps > 1 and wl.sweep_inputs[probe_k].shape[0] != B:
+        probe_k -= 1
     t0 = time.perf_counter()
     for k in range(args.steps):
         # with graph replay, ONE step of the timed region runs eagerly with a HIP-event pair around every C-ABI call of
         # the relprop path (events cannot be recorded inside a replayed graph); same kernels, same order, one stream
         # (eager configurations too: their other steps run as the library would -- relprop beside the backward pass, no events)
-        probe = k == args.steps - 1
+        probe = k == probe_k
         timer.enabled = probe and not args.no_roofline
         maps = step(eager=probe and not args.no_roofline, k=k)
     host_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (GPU still running)
     join()
     if wl.sweep:     # ONE collective for the whole sweep: every rank's [K * B, 196] block, in global order
-        gathered = parallel.gather_maps(sweep_maps.view(args.steps * B, wl.out_cols), world * args.steps * B)
+        n_sweep = SWEEP_IMAGES if (not args.batch and args.steps == -(-SWEEP_IMAGES // SWEEP_GLOBAL_BATCH)) else world * wl.sweep_local
+        gathered = parallel.gather_maps(sweep_maps, n_sweep)
     else:
         gathered = parallel.gather_maps(maps, world * B)
     torch.cuda.synchronize()
@@ -714,7 +738,8 @@ def main():
             t = t.cpu()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert gathered.shape == (world * B * (args.steps if wl.sweep else 1), wl.out_cols) and torch.isfinite(gathered).all()
+    n_units = n_sweep if wl.sweep else world * B * args.steps          # what the timed region explained, all ranks
+    assert gathered.shape == ((n_sweep if wl.sweep else world * B), wl.out_cols) and torch.isfinite(gathered).all()
     ops.x6_raise_if_failed(dev)      # sticky device word of every x6 launch of the run (no synchronisation inside a step)
 
     # Rounds stay comparable: with the x6 Linear rules the same workload is timed once more on the fp32-MFMA kernels of
@@ -765,7 +790,7 @@ def main():
             if sum(v_) > 300:
                 log(f"probe {k_[0]} gflop {k_[1]} mb {k_[2]}: n {len(v_)} us {sorted(v_)[len(v_) // 2]} (min {min(v_)}, max {max(v_)})")
     if rank == 0:
-        value = world * B * args.steps / elapsed
+        value = n_units / elapsed
         idx = CONFIGS[args.config][0]
         fused_on = args.producers == "fused" and ops.attention_forward_supported(wl.tokens, 64)
         fused_note = "attention blocks on the HIP producer kernels" if fused_on else "stock kernels throughout"
@@ -784,12 +809,19 @@ def main():
                                    f"{' (Linear rules: fp32 operands as three bf16 planes on bf16 MFMAs)' if args.linear == 'x6' else ''} (BASELINE.json "
                                    f"configs[{idx}], sharded by sample)",
                        "batch_per_gpu": B, "global_batch": world * B, "tokens": wl.tokens, "blocks": wl.blocks,
-                       **({"sweep_images": world * B * args.steps, "sweep_note": "images keyed by GLOBAL index (rank r owns the "
-                           "contiguous block r of the sweep); each step = SaliencySweep.explain (generate_LRP + bilinear x16 + "
+                       **({"sweep_images": n_units, "sweep_last_batch_per_rank": wl.sweep_inputs[-1].shape[0],
+                           "sweep_note": "parallel.sweep_layout: images keyed by GLOBAL index (rank r owns the "
+                           "contiguous block r of the sweep, walked in batches of 256 / ranks; the whole sweep ends in one short "
+                           "batch, run eagerly); each step = SaliencySweep.explain (generate_LRP + bilinear x16 + "
                            "min-max, generate_visualizations.py:60-98) of one batch; ONE all_gather of all [n,196] maps after "
                            "the last step, inside the timed region"} if wl.sweep else {}),
                        "start_layer": wl.start_layer, "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
                        "steps_in_flight": args.inflight,
+                       "x6_tile": {"option": args.x6_tile, "pin": ops.X6_TILE,
+                                   "meaning": {0: "library policy per launch (TE_X6_TILE_AUTO)", 1: "128 x 256 tiles",
+                                               2: "256 x 256 tiles where the shape allows (the step runs concurrent streams)",
+                                               3: "128 x 128 tiles"}[ops.X6_TILE],
+                                   "extra_flags": hex(ops.X6_FLAGS)},
                        "relprop_beside_backward": args.overlap_backward == "on",
                        "blocks_below_start_layer_pruned": args.prune == "on",
                        "producers": "fused attention forward/backward kernels" if fused_on else "stock",

@@ -46,15 +46,19 @@ def shard_indices(n_items: int, rank: int, world: int) -> range:
     return range(lo, hi)
 
 
-def gather_maps(local_maps: torch.Tensor, n_items: int) -> torch.Tensor:
+def gather_maps(local_maps: torch.Tensor, n_items: int, force_collective: bool = False) -> torch.Tensor:
     """All-gather the per-rank [n_local, M] maps into the full [n_items, M] tensor in global order.
     Ranks may own different counts (block partition); shards are padded to the largest for the
-    collective and trimmed afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    collective and trimmed afterwards.  force_collective (tests): issue the collective even in a
+    one-rank group, so that the device branch (RCCL all_gather_into_tensor) can be executed on a
+    single-GPU box."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_maps
+    if dist.get_world_size() == 1 and not force_collective:
         return local_maps
     world = dist.get_world_size()
     if local_maps.is_cuda and dist.get_backend() == "gloo":      # gloo has no device all_gather: stage through the host
-        return gather_maps(local_maps.cpu(), n_items).to(local_maps.device)
+        return gather_maps(local_maps.cpu(), n_items, force_collective).to(local_maps.device)
     counts = [shard_range(n_items, r, world) for r in range(world)]
     max_n = max(hi - lo for lo, hi in counts)
     M = local_maps.shape[1:]
