@@ -47,6 +47,14 @@
 
 #include "te_common.h"
 
+namespace te_attn_kb {      // te_attn_kb.hip: wave-owned key blocks (round 5) -- the default AV kernels
+bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
+int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const float* attn, const float* v,
+              int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* Z, int64_t z_sb, int64_t z_sh, int64_t z_sn,
+              float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N,
+              float scale, hipStream_t stream);
+}  // namespace te_attn_kb
+
 namespace te_attn_rules {
 
 namespace {
@@ -895,6 +903,20 @@ bool enabled() {
 #endif
 }
 
+// which AV kernels run: 1 (default) = te_attn_kb.hip (wave-owned key blocks), 0 = av_rule_kernel above (round 2).
+// TE_ATTN_AV=old selects the round-2 kernel in measurement builds (-DTE_STUDY) for same-box A/B runs.
+static bool use_kb_av() {
+#ifdef TE_STUDY
+  static const bool on = [] {
+    const char* e = getenv("TE_ATTN_AV");
+    return !(e && !strcmp(e, "old"));
+  }();
+  return on;
+#else
+  return true;
+#endif
+}
+
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   int ng, jg;
   groups_for(N, ng, jg);
@@ -910,6 +932,9 @@ int av_launch(const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn, const fl
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
   if (r_sn > 65536 || z_sn > 65536) return TE_ERR_UNSUPPORTED;      // 32-bit row offsets inside a (b, h) view
+  if (use_kb_av() && te_attn_kb::supported(B, H, N, 64))
+    return te_attn_kb::av_launch(0, R, r_sb, r_sh, r_sn, attn, v, v_sb, v_sh, v_sn, Z, z_sb, z_sh, z_sn, cam_attn, cam_v, cv_sb,
+                                 cv_sh, cv_sn, B, H, N, scale, stream);
   allow_lds(av_rule_kernel<RULE>, lds_av(256));
   av_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), lds_av(jg), stream>>>(
       R, Strided{r_sb, r_sh, r_sn}, Z, Strided{z_sb, z_sh, z_sn}, attn, v, Strided{v_sb, v_sh, v_sn}, cam_attn, cam_v,
@@ -976,10 +1001,16 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
   int ng, jg;
   groups_for(N, ng, jg, 256);                   // N <= 224: one group (the softmax backward needs every key of a row)
   // d_attn = d_out v^T ; d_v = attn^T d_out
-  allow_lds(av_rule_kernel<BWD>, lds_av(256));
-  av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), lds_av(jg), stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
-                                                                      qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
-                                                                      (int)H, (int)N, BH, jg, 1.0f, nullptr);
+  if (use_kb_av() && te_attn_kb::supported(B, H, N, 64)) {
+    int rc = te_attn_kb::av_launch(1, d_out, heads.sb, heads.sh, heads.sn, attn, qkv + 2 * C, fused.sb, fused.sh, fused.sn,
+                                   nullptr, 0, 0, 0, d_attn, d_qkv + 2 * C, fused.sb, fused.sh, fused.sn, B, H, N, 1.0f, stream);
+    if (rc != TE_OK) return rc;
+  } else {
+    allow_lds(av_rule_kernel<BWD>, lds_av(256));
+    av_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), lds_av(jg), stream>>>(d_out, heads, nullptr, Strided{0, 0, 0}, attn,
+                                                                        qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
+                                                                        (int)H, (int)N, BH, jg, 1.0f, nullptr);
+  }
   if (need_qk) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q
     allow_lds(qk_rule_kernel<BWD>, lds_qk(256, true));
