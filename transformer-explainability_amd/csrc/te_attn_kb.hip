@@ -22,6 +22,8 @@
 // ds_read_b32 and ~40 vector-ALU instructions: < 2 other instructions per 64-cycle fp32 MFMA.
 //
 // Reductions run in an order that depends on N only: a batch equals its samples run one by one, bit for bit.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "te_common.h"
@@ -33,6 +35,7 @@ namespace {
 constexpr int TI = 32;         // query rows per tile
 constexpr int kT = 512;        // threads per workgroup
 constexpr int kWaves = kT / 64;
+constexpr int XLD = 36;        // row stride (floats) of a wave's [32][32] staging block
 constexpr int SLD = 68;        // row stride (floats) of the [32][64] row-side tile in LDS: conflict-free 16-B fragment reads
 
 struct Strided {  // [B,H,N,64] view, 64 contiguous
@@ -75,6 +78,21 @@ __device__ __forceinline__ void st32(float x, Rsrc r, unsigned voff) {
 // out of order and drains vmcnt to zero before every use of a loaded value; hidden, the loads alone are counted exactly.
 // Safe: vmcnt counts these stores too, so a wait hipcc computes for its loads can only wait longer than it thinks, never
 // shorter (loads retire in order among themselves); the store data is read at issue (no expcnt for VMEM stores on gfx9+).
+// Loads hipcc's s_waitcnt insertion does not see either: across a loop back-edge it loses the age order of in-flight loads
+// and waits vmcnt(0) at the first use of ANY of them -- a full drain of the prefetch pipeline once per tile.  The tile loop
+// therefore issues all its global loads and stores as inline asm and waits with hand-counted s_waitcnt vmcnt(n), n = the
+// number of YOUNGER LOADS in flight (stores are never counted: loads retire in order among themselves, and a store that
+// retires late only makes the wait longer).  After the wait, TE_PIN makes the value's first use follow it in program order.
+__device__ __forceinline__ f32x4 ld128_hidden(Rsrc r, unsigned voff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(r));
+  return v;
+}
+#define TE_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define TE_PIN(v) asm volatile("" : "+v"(v))
+__device__ __forceinline__ void st128_hidden(f32x4 x, Rsrc r, unsigned voff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(x), "v"(voff), "s"(r));
+}
 __device__ __forceinline__ void st32_hidden(float x, Rsrc r, unsigned voff) {
   asm volatile("buffer_store_dword %0, %1, %2, 0 offen" : : "v"(x), "v"(voff), "s"(r));
 }
@@ -85,15 +103,53 @@ __device__ __forceinline__ void st32_hidden(float x, Rsrc r, unsigned voff) {
 // R, Z strided [B,H,N,64]; attn, cam_attn contiguous [B*H,N,N]; v, cam_v strided.
 // grid = BH * ngroups (bh fastest); workgroup g of a (b, h) owns key blocks [g KBG, (g + 1) KBG), wave w block g KBG + w.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+// PROF (measurement builds: -DTE_STUDY, TE_ATTN_KB_PROF=1): workgroup 0 accumulates shader-clock cycles per wave and phase
+#ifdef TE_STUDY
+__device__ long long g_kb_prof[kWaves * 8];
+#endif
+#define KB_MARK(slot)                                                     \
+  do {                                                                    \
+    if constexpr (PROF) {                                                 \
+      if (blockIdx.x == 0 && lane == 0) {                                 \
+        const long long now__ = clock64();                                \
+        prof_acc[slot] += now__ - tprev;                                  \
+        tprev = now__;                                                    \
+      }                                                                   \
+    }                                                                     \
+  } while (0)
+
+// STUDY (measurement builds, TE_ATTN_KB_STUDY=n; results are garbage): 1 no N x N stores, 2 no N x N loads, 4 no row product,
+// 5 no column product, 8 no MFMA at all, 9 no N x N loads and no stores
+template <int MODE, bool PROF = false, int STUDY = 0>
 __global__ __launch_bounds__(kT) void av_kb_kernel(
     const float* __restrict__ R, Strided rs, const float* __restrict__ Z, Strided zs, const float* __restrict__ attn,
     const float* __restrict__ v, Strided vs, float* __restrict__ cam_attn, float* __restrict__ cam_v, Strided cs, int H,
     int N, int BH, int KBG, float scale) {
-  __shared__ __attribute__((aligned(16))) float St[2][TI * SLD];
+  // Row-side tiles in LDS: THREE buffers and an arrival counter instead of a barrier per tile.  S(k) lives in buffer k % 3; a
+  // wave that has written its part of S(k) adds 1 to `arrived` (LDS operations of a wave execute in order: the add follows
+  // its write); S(k) is complete at 8 (k + 1).  In iteration it every wave first waits for S(it) -- complete since the other
+  // waves' previous iteration, so the poll normally falls through -- then writes its part of S(it + 1) over S(it - 2), whose
+  // last readers (the MFMAs of iteration it - 2) every wave finished before it contributed to S(it).  No wave ever waits for
+  // another wave's MFMAs: measured with s_barrier per tile (scripts/attn_kb_prof.py), the older wave of a SIMD ran its 64
+  // MFMAs at full rate, the younger one's only started when those had finished (issue arbitration prefers the older wave,
+  // whose dependent MFMA is always ready), and then BOTH waited at the barrier and formed the next S with the matrix pipe
+  // idle: 12 500 cycles per tile for 8 200 cycles of MFMAs.
+  __shared__ __attribute__((aligned(16))) float St[3][TI * SLD];
+  __shared__ unsigned arrived;
+  // Wave-private staging of the wave's [32 rows x 32 keys] blocks: the N x N operand is read and the N x N result written as
+  // 16-byte pieces per lane -- lane l moves keys 4 (l & 7) .. + 3 of row 8 p + (l >> 3), four instructions per block, each
+  // covering eight rows x 128 contiguous bytes -- and changes to / from the accumulator layout through LDS (no barrier: a
+  // wave's LDS instructions execute in order).  Measured (profiles/r05_attention_av_kb_study.log): with one dword per lane
+  // and instruction (16 + 16 instructions per block) the stores alone cost 57 of the kernel's 130 us at N = 197.
+  __shared__ __attribute__((aligned(16))) float Xw[kWaves][2][TI * XLD];
+  if (threadIdx.x == 0) arrived = 0;
+  __syncthreads();
   const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
   const int b = bh / H, h = bh - b * H;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = PROF ? clock64() : 0;
+  (void)prof_acc;
   const int nkb = (N + 31) >> 5, kb = g * KBG + wave;
   const bool has_blk = wave < KBG && kb < nkb;            // wave-uniform
   const int j = kb * 32 + lr;                             // this lane's key
@@ -119,8 +175,13 @@ __global__ __launch_bounds__(kT) void av_kb_kernel(
   const unsigned r_off = ((unsigned)srow * (unsigned)rs.sn + 4u * sc) * 4u, z_off = ((unsigned)srow * (unsigned)zs.sn + 4u * sc) * 4u;
   const unsigned r_tile = (unsigned)TI * (unsigned)rs.sn * 4u, z_tile = (unsigned)TI * (unsigned)zs.sn * 4u;
   auto fetch_rz = [&](int it) __attribute__((always_inline)) {          // (any it: tiles beyond the last read zeros)
-    rr = ld128(r_rs, r_off + (unsigned)it * r_tile);
-    if constexpr (MODE == RULE) zz = ld128(z_rs, z_off + (unsigned)it * z_tile);
+    rr = ld128_hidden(r_rs, r_off + (unsigned)it * r_tile);
+    if constexpr (MODE == RULE) zz = ld128_hidden(z_rs, z_off + (unsigned)it * z_tile);
+  };
+  constexpr int kRz = (MODE == RULE) ? 2 : 1;      // loads per fetch_rz
+  auto pin_rz = [&]() __attribute__((always_inline)) {
+    TE_PIN(rr);
+    if constexpr (MODE == RULE) TE_PIN(zz);
   };
   auto put_s = [&](int it) __attribute__((always_inline)) {
     f32x4 s = rr;                                                   // BWD: the tile of d_out itself
@@ -128,20 +189,37 @@ __global__ __launch_bounds__(kT) void av_kb_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);       // rows beyond N: sd(0, 0) = 0
     }
-    *reinterpret_cast<f32x4*>(&St[it & 1][srow * SLD + (sc << 2)]) = s;
+    *reinterpret_cast<f32x4*>(&St[it % 3][srow * SLD + (sc << 2)]) = s;
+    // RELAXED atomics + compiler barriers, NOT release / acquire: data and counter both live in LDS, whose instructions a
+    // wave executes in order, so the hardware needs nothing more -- while hipcc turns a workgroup-scope acquire (and a
+    // __syncthreads()) into s_waitcnt vmcnt(0), i.e. a full drain of the wave's global-memory pipeline at every tile: the
+    // prefetches just issued, two tiles ahead, and the stores (found in the ISA after the phase profile showed every wave
+    // waiting ~2 500 cycles where it forms S: with the drain the kernel's time was memory time PLUS MFMA time)
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_s = [&](int it) __attribute__((always_inline)) {            // S(it) complete
+    const unsigned target = (unsigned)kWaves * (unsigned)(it + 1);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
   };
 
   if (!has_blk) {
     // a wave without a key block (N = 197: wave 7) only helps to form the row-side tiles
     fetch_rz(0);
+    TE_VM_WAIT(0);
+    pin_rz();
     put_s(0);
     fetch_rz(1);
-    __syncthreads();
     for (int it = 0; it < ntiles; ++it) {
+      wait_s(it);                                  // (throttle: S(it + 1) overwrites S(it - 2))
+      TE_VM_WAIT(0);                               // R / Z of tile it + 1: this wave's only requests
+      pin_rz();
       put_s(it + 1);
       fetch_rz(it + 2);
-      __syncthreads();
     }
+    TE_VM_WAIT(0);
     return;
   }
 
@@ -154,18 +232,45 @@ __global__ __launch_bounds__(kT) void av_kb_kernel(
   }
   // the wave's [32 rows x 32 keys] block of an N x N operand in accumulator layout: element e = row i0 + crow(e, kh), key j
   const unsigned lane_nn = ((unsigned)(4 * kh) * (unsigned)N + (unsigned)j) * 4u;
-  auto fetch_attn = [&](int it, float (&dst)[16]) __attribute__((always_inline)) {
+  float* const Ax = Xw[wave][0];                  // attn block: rows in, accumulator layout out
+  float* const Gx = Xw[wave][1];                  // result block: accumulator layout in, rows out
+  const int xr = lane >> 3, xc = (lane & 7) << 2;                  // this lane's row (+ 8 p) and first key of a 16-byte piece
+  const unsigned lane_x4 = ((unsigned)xr * (unsigned)N + (unsigned)(kb * 32 + xc)) * 4u;
+  auto fetch_attn = [&](int it, f32x4 (&dst)[4]) __attribute__((always_inline)) {
     const unsigned base = (unsigned)(it * TI) * row_bytes;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) dst[e] = ld32(a_rs, lane_nn + (base + (unsigned)((e & 3) + 8 * (e >> 2)) * row_bytes));
+    for (int p = 0; p < 4; ++p) {
+      if constexpr (STUDY != 2 && STUDY != 9) dst[p] = ld128_hidden(a_rs, lane_x4 + (base + (unsigned)(8 * p) * row_bytes));
+      else dst[p] = f32x4{0.25f, 0.5f, 0.75f, 1.0f};
+    }
+  };
+  auto to_acc = [&](const f32x4 (&src)[4], float (&dst)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(Ax + (8 * p + xr) * XLD + xc) = src[p];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[e] = Ax[crow(e, kh) * XLD + lr];
   };
 
-  float ac[16], an[16];
+  // attn blocks are requested TWO tiles ahead (an2), so that the change of layout at a tile's end (an -> ac) never waits for
+  // memory: with one tile of lookahead every wave's non-MFMA chain contained an HBM round trip, and a SIMD's two waves can
+  // only cover each other's chains while those are shorter than an MFMA block (4 400 cycles)
+  float ac[16];
+  f32x4 an[4], an2[4];
   fetch_rz(0);
-  fetch_attn(0, ac);
+  fetch_attn(0, an2);
+  TE_VM_WAIT(0);                                   // (prologue: hipcc's own loads of vf above included)
+  pin_rz();
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) TE_PIN(vf[kg]);   // (hipcc's own wait for vf lands HERE, not at vf's first use inside the loop,
+                                                   //  where the merged loop-header state would repeat it every iteration)
+#pragma unroll
+  for (int p = 0; p < 4; ++p) TE_PIN(an2[p]);
   put_s(0);
   fetch_rz(1);
-  __syncthreads();
+  fetch_attn(1, an);
+  to_acc(an2, ac);
+  // In flight when the loop starts, oldest first: R / Z(1), attn(1) -- the order every iteration keeps: it issues the stores
+  // of tile it - 1, then R / Z(it + 2), then attn(it + 2).
 
   f32x16 accv[2];
   zero16(accv[0]);
@@ -179,63 +284,105 @@ __global__ __launch_bounds__(kT) void av_kb_kernel(
   f32x16 gp;                                       // cam_attn / d_attn block of the previous tile, not yet stored
   zero16(gp);
   const bool key_ok = j < N;
-  auto store_g = [&](int it_prev) __attribute__((always_inline)) {
-    if (key_ok) {                                  // (rows beyond N: dropped by the range check)
-      const unsigned base = (unsigned)(it_prev * TI) * row_bytes;
+  const bool blk_full = kb * 32 + 32 <= N;         // wave-uniform: every key of the block exists (else: dword stores, masked)
+  auto stage_g = [&]() __attribute__((always_inline)) {               // the tile's result -> rows (full key blocks)
+    if (blk_full) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st32_hidden(gp[e], ca_rs, lane_nn + (base + (unsigned)((e & 3) + 8 * (e >> 2)) * row_bytes));
+      for (int e = 0; e < 16; ++e) Gx[crow(e, kh) * XLD + lr] = gp[e];
+    }
+  };
+  auto store_g = [&](int it_prev) __attribute__((always_inline)) {    // (rows beyond N: dropped by the range check)
+    const unsigned base = (unsigned)(it_prev * TI) * row_bytes;
+    if (blk_full) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(Gx + (8 * p + xr) * XLD + xc);
+        if constexpr (STUDY != 1 && STUDY != 9) st128_hidden(t, ca_rs, lane_x4 + (base + (unsigned)(8 * p) * row_bytes));
+      }
+    } else if (key_ok) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if constexpr (STUDY != 1 && STUDY != 9) st32_hidden(gp[e], ca_rs, lane_nn + (base + (unsigned)((e & 3) + 8 * (e >> 2)) * row_bytes));
     }
   };
   // FULL = all 32 rows exist (every tile but, for N % 32 != 0, the last)
-  auto tile = [&](int it, auto full_tag) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const int i0 = it * TI;
-    const float* Sc = St[it & 1];
-    put_s(it + 1);                                 // (its buffer's last readers finished before the previous barrier)
+  // (ax = the register set the attn block of tile it + 2 is requested into, ay = the set that holds tile it + 1's, requested
+  // by the previous iteration: the callers alternate the two sets -- a register with a load in flight must not be copied)
+  auto tile = [&](int it, f32x4 (&ax)[4], f32x4 (&ay)[4]) __attribute__((always_inline)) {
+    const float* Sc = St[it % 3];
+    KB_MARK(5);                                    // to_acc of the previous tile's end + loop overhead
+    wait_s(it);
+    KB_MARK(4);                                    // poll for S(it)
+    // R / Z(it + 1) were requested a tile ago (iteration 0: in the prologue); younger loads in flight: attn(it + 1)
+    if constexpr (STUDY != 2 && STUDY != 9) TE_VM_WAIT(4);
+    else TE_VM_WAIT(0);
+    pin_rz();
+    put_s(it + 1);
+    KB_MARK(6);                                    // S(it + 1): wait for R / Z, sd, LDS write, arrive
     if (it > 0) store_g(it - 1);
     fetch_rz(it + 2);
-    fetch_attn(it + 1, an);
+    fetch_attn(it + 2, ax);
     __builtin_amdgcn_sched_barrier(0);             // (hipcc otherwise sinks the requests to the END of the tile's MFMAs)
-    // ---- row side: G = S v^T for this wave's key block; cam_attn = attn . G straight from the accumulators ----
-    f32x16 gacc;
-    zero16(gacc);
-    {
-      const float* Ap = Sc + lr * SLD + 4 * kh;
-      f32x4 a[8];
+    KB_MARK(0);                                    // tile top: waits, S(it + 1), memory burst
+    if (it < ntiles) {                             // (the pair loop runs one tile beyond an odd tile count: no products there)
+      // ---- row side: G = S v^T for this wave's key block; cam_attn = attn . G straight from the accumulators ----
+      f32x16 gacc;
+      zero16(gacc);
+      {
+        const float* Ap = Sc + lr * SLD + 4 * kh;
+        f32x4 a[8];
 #pragma unroll
-      for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const f32x4*>(Ap + 8 * kg);
+        for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const f32x4*>(Ap + 8 * kg);
 #pragma unroll
-      for (int kg = 0; kg < 8; ++kg)
+        for (int kg = 0; kg < 8; ++kg)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) gacc = TE_MFMA32(a[kg][jj], vf[kg][jj], gacc);
-    }
-    // ---- column side: cam_v += attn^T S (keys x 64), K = the 32 query rows in accumulator order ----
-    const int kgmax = FULL ? 4 : (N - i0 + 7) >> 3;          // rows of the last tile beyond N are zero in S: skipped
+          for (int jj = 0; jj < 4; ++jj) {
+            if constexpr (STUDY != 4 && STUDY != 8) gacc = TE_MFMA32(a[kg][jj], vf[kg][jj], gacc);
+            else gacc[jj] += a[kg][jj] * vf[kg][jj];
+          }
+      }
+      KB_MARK(1);                                  // row product issued
+      // ---- column side: cam_v += attn^T S (keys x 64), K = the 32 query rows in accumulator order (rows beyond N are zero
+      // in S and in attn: no special case, the last tile of N = 197 spends 24 of its 64 MFMAs on them) ----
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const float* Yp = Sc + kh * 4 * SLD + db * 32 + lr;
-      float bq[16];
+      for (int db = 0; db < 2; ++db) {
+        const float* Yp = Sc + kh * 4 * SLD + db * 32 + lr;
+        float bq[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) bq[e] = Yp[((e & 3) + 8 * (e >> 2)) * SLD];
+        for (int e = 0; e < 16; ++e) bq[e] = Yp[((e & 3) + 8 * (e >> 2)) * SLD];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        if (FULL || g4 < kgmax) {
-#pragma unroll
-          for (int e = 4 * g4; e < 4 * g4 + 4; ++e) accv[db] = TE_MFMA32(ac[e], bq[e], accv[db]);
+        for (int e = 0; e < 16; ++e) {
+          if constexpr (STUDY != 5 && STUDY != 8) accv[db] = TE_MFMA32(ac[e], bq[e], accv[db]);
+          else accv[db][e] += ac[e] * bq[e];
         }
       }
+      KB_MARK(2);                                  // column product issued
+      // ---- the N x N result of this tile: stored at the top of the next one ----
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gp[e] = (MODE == RULE) ? (ac[e] * gacc[e]) * scale : gacc[e];
+      stage_g();
+      KB_MARK(3);                                  // N x N result formed (the row product's MFMAs have finished)
     }
-    // ---- the N x N result of this tile: stored at the top of the next one ----
+    // attn(it + 1) was requested a tile ago; younger loads in flight: R / Z(it + 2) and attn(it + 2) of this tile
+    if constexpr (STUDY != 2 && STUDY != 9) {
+      if constexpr (kRz == 2) TE_VM_WAIT(6);
+      else TE_VM_WAIT(5);
+    }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) gp[e] = (MODE == RULE) ? (ac[e] * gacc[e]) * scale : gacc[e];
-    __syncthreads();                               // S(it + 1) is published; S(it)'s buffer is free
-#pragma unroll
-    for (int e = 0; e < 16; ++e) ac[e] = an[e];
+    for (int p = 0; p < 4; ++p) TE_PIN(ay[p]);
+    to_acc(ay, ac);                                // the next tile's attn block
   };
-  const int nfull = N / TI;
-  for (int it = 0; it < nfull; ++it) tile(it, std::true_type{});
-  if (nfull < ntiles) tile(nfull, std::false_type{});
-  store_g(ntiles - 1);
+  KB_MARK(7);                                      // prologue
+  // ONE loop body for every tile (two tiles per trip, the register sets swapping roles): hipcc may copy a loop-carried
+  // register where control flow forks -- a separate code path for the last tile read such a copy of a register whose load was
+  // still in flight (wrong rows 192..196 at N = 197 until the tail was folded into the loop)
+#pragma unroll 1
+  for (int it = 0; it < ntiles; it += 2) {
+    tile(it, an2, an);
+    tile(it + 1, an, an2);
+  }
+  TE_VM_WAIT(0);                                   // (requests beyond the last tile: zeros, but their registers are in flight)
+  if ((ntiles & 1) == 0) store_g(ntiles - 1);      // (odd tile count: the trip beyond the last tile has stored it)
 
   // ---- column epilogue: accv[db][e] = (attn^T S)[key = 32 kb + crow(e, kh)][d = 32 db + lr]; keys beyond N: dropped ----
 #pragma unroll
@@ -255,6 +402,13 @@ __global__ __launch_bounds__(kT) void av_kb_kernel(
       st32(val, cv_rs, ooff + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)cs.sn * 4u);
     }
   }
+#ifdef TE_STUDY
+  if constexpr (PROF) {
+    KB_MARK(7);                                    // prologue + last store burst + column epilogue (issue only)
+    if (blockIdx.x == 0 && lane == 0)
+      for (int q = 0; q < 8; ++q) g_kb_prof[wave * 8 + q] = prof_acc[q];
+  }
+#endif
 }
 
 // key blocks per workgroup: at most eight (one per wave), the blocks of a (b, h) spread evenly over ceil(nkb / 8) workgroups
@@ -284,6 +438,20 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
   if (r_sn > 65536 || z_sn > 65536) return TE_ERR_UNSUPPORTED;      // 32-bit row offsets inside a (b, h) view
   const dim3 grid((unsigned)(BH * ng)), blk(kT);
   const Strided rs{r_sb, r_sh, r_sn}, zs{z_sb, z_sh, z_sn}, vs{v_sb, v_sh, v_sn}, cs{cv_sb, cv_sh, cv_sn};
+#ifdef TE_STUDY
+  if (mode == 0) {
+    const char* se = getenv("TE_ATTN_KB_STUDY");
+    const int st = se ? atoi(se) : 0;
+#define TE_KB_ST(n) if (st == n) { av_kb_kernel<RULE, false, n><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale); return TE_OK; }
+    TE_KB_ST(1) TE_KB_ST(2) TE_KB_ST(4) TE_KB_ST(5) TE_KB_ST(8) TE_KB_ST(9)
+#undef TE_KB_ST
+    const char* e = getenv("TE_ATTN_KB_PROF");
+    if (e && atoi(e) == 1) {
+      av_kb_kernel<RULE, true><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
+      return TE_OK;
+    }
+  }
+#endif
   if (mode == 0)
     av_kb_kernel<RULE><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
   else
@@ -293,3 +461,12 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
 }
 
 }  // namespace te_attn_kb
+
+#ifdef TE_STUDY
+// measurement builds: the phase counters of the last profiled launch (8 waves x 8 slots), synchronising
+extern "C" int te_attn_kb_prof_read(long long* host_out) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(te_attn_kb::g_kb_prof), sizeof(long long) * 64);
+}
+#endif
