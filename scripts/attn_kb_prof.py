@@ -29,7 +29,7 @@ fn = lib.te_attn_kb_prof_read
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 assert fn(buf) == 0
-names = ["stores+requests", "row product", "col product", "result->LDS", "poll S", "to_acc+loop", "form S", "pro+epilogue"]
+names = ["requests", "row product", "split+col product", "result+stores", "poll S", "to_acc+loop", "form S", "pro+epilogue"]
 ntiles = (N + 31) // 32
 print(f"B={B} H={H} N={N}: {ntiles} tiles; cycles per wave of workgroup 0 (per tile in brackets)")
 for w in range(8):

@@ -23,6 +23,7 @@
 //
 // Reductions run in an order that depends on N only: a batch equals its samples run one by one, bit for bit.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -411,6 +412,313 @@ __global__ __launch_bounds__(kT) void av_kb_kernel(
 #endif
 }
 
+// ================================================================================================
+// The same kernel on bf16 MFMAs at fp32 accuracy ("x6", as te_linear_x6.hip): every fp32 operand is the exact sum of three
+// bf16 planes, the six partial products above 2^-24 are kept (a1 b1 + a0 b2 + a2 b0 + a0 b1 + a1 b0 + a0 b0, smallest first),
+// fp32 accumulation.  Why here: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and its time ADDS to the vector-ALU time
+// of the SIMD's waves (per-wave phase profile, profiles/r05_attention_av_kb_phase_profile.log: MFMA blocks at full rate,
+// every other phase 2-3x longer while the partner wave multiplies; tile = 8 200 MFMA cycles + ~4 000 others), while the
+// bf16 matrix pipe is a separate unit: 48 MFMAs of 32 cycles per tile and wave instead of 64 of 64, beside ~300 vector
+// instructions (sd, the three-way splits, the result's factor).
+//   row product   G = S v^T:  A = S planes [row][d] from LDS (16-byte fragments, K = d in four steps of 16), B = v planes of
+//                 the wave's 32 keys, resident in 48 registers
+//   column product  cam_v += attn^T S:  A = the attn block's planes, split in registers from the accumulator-layout values
+//                 (K step s covers rows crow(8 s .. 8 s + 7, kh): the contraction order is free), B = S planes TRANSPOSED
+//                 [d][row position] from LDS, the row positions permuted to that order (pos = row with bits 2 and 3 swapped)
+// The S producer (all 512 threads, one float4 each) writes both plane images of its tile.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define TE_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// x = p[0] + p[1] + p[2] exactly (te_linear_x6.hip: split3_pk); p[q] = the packed pair (x0 low half, x1 high half) of plane q
+__device__ __forceinline__ void split3_pk(float x0, float x1, unsigned (&p)[3]) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+    p[q] = u;
+    x0 = x0 - __builtin_bit_cast(float, u << 16);
+    x1 = x1 - __builtin_bit_cast(float, u & 0xffff0000u);
+  }
+}
+// eight consecutive K values -> one MFMA operand fragment per plane
+__device__ __forceinline__ void split3_x8(const float (&x)[8], bf16x8 (&pl)[3]) {
+  unsigned w[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split3_pk(x[2 * i], x[2 * i + 1], w[i]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) pl[q] = __builtin_bit_cast(bf16x8, u32x4{w[0][q], w[1][q], w[2][q], w[3][q]});
+}
+// acc += a b with the six partial products, smallest first
+__device__ __forceinline__ void mfma_x6(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+  acc = TE_MFMA_BF16(a[1], b[1], acc);
+  acc = TE_MFMA_BF16(a[0], b[2], acc);
+  acc = TE_MFMA_BF16(a[2], b[0], acc);
+  acc = TE_MFMA_BF16(a[0], b[1], acc);
+  acc = TE_MFMA_BF16(a[1], b[0], acc);
+  acc = TE_MFMA_BF16(a[0], b[0], acc);
+}
+
+constexpr int kRLD = 144;                  // bytes per row of a row-major S plane [32 rows][64 d] (128 + 16: conflict-free b128)
+constexpr int kTLD = 80;                   // bytes per row of a transposed S plane [64 d][32 row positions] (64 + 16)
+constexpr int kPlR = TI * kRLD;            // 4 608
+constexpr int kPlT = 64 * kTLD;            // 5 120
+constexpr int kSBuf = 3 * kPlR + 3 * kPlT; // 29 184 bytes per S tile: both images, three planes each
+
+template <int MODE, bool PROF = false>
+__global__ __launch_bounds__(kT) void av6_kb_kernel(
+    const float* __restrict__ R, Strided rs, const float* __restrict__ Z, Strided zs, const float* __restrict__ attn,
+    const float* __restrict__ v, Strided vs, float* __restrict__ cam_attn, float* __restrict__ cam_v, Strided cs, int H,
+    int N, int BH, int KBG, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char Sb[3][kSBuf];       // S(k) lives in buffer k % 3 (see av_kb_kernel)
+  __shared__ __attribute__((aligned(16))) float Xw[kWaves][TI * XLD];      // wave-private: layout changes of the N x N blocks
+  __shared__ unsigned arrived;
+  if (threadIdx.x == 0) arrived = 0;
+  __syncthreads();
+  const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
+  const int b = bh / H, h = bh - b * H;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = PROF ? clock64() : 0;
+  (void)prof_acc;
+  const int nkb = (N + 31) >> 5, kb = g * KBG + wave;
+  const bool has_blk = wave < KBG && kb < nkb;            // wave-uniform
+  const int j = kb * 32 + lr;                             // this lane's key
+  const int ntiles = (N + TI - 1) / TI;
+  const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;      // this thread's float4 of the [32][64] row-side tile
+  const int spos = (srow & 0x13) | ((srow & 4) << 1) | ((srow & 8) >> 1);      // its row's position in the transposed image
+
+  const unsigned nn_bytes = (unsigned)N * (unsigned)N * 4u;
+  const Rsrc a_rs = make_rsrc(attn + (int64_t)bh * N * N, nn_bytes);
+  const Rsrc ca_rs = make_rsrc(cam_attn + (int64_t)bh * N * N, nn_bytes);
+  const Rsrc r_rs = make_rsrc(R + (int64_t)b * rs.sb + (int64_t)h * rs.sh, view_bytes(N, rs.sn));
+  const Rsrc z_rs = make_rsrc(MODE == RULE ? Z + (int64_t)b * zs.sb + (int64_t)h * zs.sh : R, MODE == RULE ? view_bytes(N, zs.sn) : 0u);
+  const Rsrc v_rs = make_rsrc(v + (int64_t)b * vs.sb + (int64_t)h * vs.sh, view_bytes(N, vs.sn));
+  const Rsrc cv_rs = make_rsrc(cam_v + (int64_t)b * cs.sb + (int64_t)h * cs.sh, view_bytes(N, cs.sn));
+  const unsigned row_bytes = (unsigned)N * 4u;
+
+  f32x4 rr = {0.f, 0.f, 0.f, 0.f}, zz = {0.f, 0.f, 0.f, 0.f};
+  const unsigned r_off = ((unsigned)srow * (unsigned)rs.sn + 4u * sc) * 4u, z_off = ((unsigned)srow * (unsigned)zs.sn + 4u * sc) * 4u;
+  const unsigned r_tile = (unsigned)TI * (unsigned)rs.sn * 4u, z_tile = (unsigned)TI * (unsigned)zs.sn * 4u;
+  auto fetch_rz = [&](int it) __attribute__((always_inline)) {          // (any it: tiles beyond the last read zeros)
+    rr = ld128_hidden(r_rs, r_off + (unsigned)it * r_tile);
+    if constexpr (MODE == RULE) zz = ld128_hidden(z_rs, z_off + (unsigned)it * z_tile);
+  };
+  constexpr int kRz = (MODE == RULE) ? 2 : 1;
+  auto pin_rz = [&]() __attribute__((always_inline)) {
+    TE_PIN(rr);
+    if constexpr (MODE == RULE) TE_PIN(zz);
+  };
+  // S(it) of this thread's four elements -> both plane images of buffer it % 3, then arrive (see av_kb_kernel::put_s)
+  auto put_s = [&](int it) __attribute__((always_inline)) {
+    f32x4 s = rr;
+    if constexpr (MODE == RULE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = te_sd(rr[e], zz[e]);       // rows beyond N: sd(0, 0) = 0
+    }
+    unsigned p01[3], p23[3];
+    split3_pk(s[0], s[1], p01);
+    split3_pk(s[2], s[3], p23);
+    unsigned char* base = Sb[it % 3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      *reinterpret_cast<u32x2*>(base + q * kPlR + srow * kRLD + sc * 8) = u32x2{p01[q], p23[q]};
+      unsigned char* t = base + 3 * kPlR + q * kPlT + (4 * sc) * kTLD + spos * 2;
+      *reinterpret_cast<unsigned short*>(t) = (unsigned short)(p01[q] & 0xffffu);
+      *reinterpret_cast<unsigned short*>(t + kTLD) = (unsigned short)(p01[q] >> 16);
+      *reinterpret_cast<unsigned short*>(t + 2 * kTLD) = (unsigned short)(p23[q] & 0xffffu);
+      *reinterpret_cast<unsigned short*>(t + 3 * kTLD) = (unsigned short)(p23[q] >> 16);
+    }
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_s = [&](int it) __attribute__((always_inline)) {            // S(it) complete
+    const unsigned target = (unsigned)kWaves * (unsigned)(it + 1);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+
+  if (!has_blk) {
+    fetch_rz(0);
+    TE_VM_WAIT(0);
+    pin_rz();
+    put_s(0);
+    fetch_rz(1);
+    for (int it = 0; it < ntiles; ++it) {
+      wait_s(it);                                  // (throttle: S(it + 1) overwrites S(it - 2))
+      TE_VM_WAIT(0);
+      pin_rz();
+      put_s(it + 1);
+      fetch_rz(it + 2);
+    }
+    TE_VM_WAIT(0);
+    return;
+  }
+
+  // key-side operand of the row product, resident: the planes of v[j][16 s + 8 kh + 0..7], s = 0..3 (keys beyond N: zeros)
+  bf16x8 vpl[4][3];
+  {
+    const unsigned off = ((unsigned)j * (unsigned)vs.sn + 8u * kh) * 4u;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const f32x4 lo = ld128(v_rs, off + 64u * s4), hi = ld128(v_rs, off + 64u * s4 + 16u);
+      const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      split3_x8(x, vpl[s4]);
+    }
+  }
+  float* const Xb = Xw[wave];
+  const int xr = lane >> 3, xc = (lane & 7) << 2;                  // this lane's row (+ 8 p) and first key of a 16-byte piece
+  const unsigned lane_x4 = ((unsigned)xr * (unsigned)N + (unsigned)(kb * 32 + xc)) * 4u;
+  const unsigned lane_nn = ((unsigned)(4 * kh) * (unsigned)N + (unsigned)j) * 4u;
+  const bool key_ok = j < N;
+  const bool blk_full = kb * 32 + 32 <= N;         // wave-uniform: every key of the block exists (else: dword stores, masked)
+  auto fetch_attn = [&](int it, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+    const unsigned base = (unsigned)(it * TI) * row_bytes;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dst[p] = ld128_hidden(a_rs, lane_x4 + (base + (unsigned)(8 * p) * row_bytes));
+  };
+  auto to_acc = [&](const f32x4 (&src)[4], float (&dst)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(Xb + (8 * p + xr) * XLD + xc) = src[p];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[e] = Xb[crow(e, kh) * XLD + lr];
+  };
+
+  float ac[16];
+  f32x4 an[4], an2[4];
+  fetch_rz(0);
+  fetch_attn(0, an2);
+  TE_VM_WAIT(0);                                   // (prologue: hipcc's own loads of v above included)
+  pin_rz();
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) TE_PIN(vpl[s4][q]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) TE_PIN(an2[p]);
+  put_s(0);
+  fetch_rz(1);
+  fetch_attn(1, an);
+  to_acc(an2, ac);
+  // In flight when the loop starts, oldest first: R / Z(1), attn(1).  Every iteration issues R / Z(it + 2), attn(it + 2) at
+  // its top and the stores of its own result at its end.
+
+  f32x16 accv[2];
+  zero16(accv[0]);
+  zero16(accv[1]);
+  auto tile = [&](int it, f32x4 (&ax)[4], f32x4 (&ay)[4]) __attribute__((always_inline)) {
+    const unsigned char* Sc = Sb[it % 3];
+    KB_MARK(5);                                    // to_acc of the previous tile's end + loop overhead
+    wait_s(it);
+    KB_MARK(4);                                    // poll for S(it)
+    TE_VM_WAIT(4);                                 // R / Z(it + 1): younger loads in flight = attn(it + 1)
+    pin_rz();
+    put_s(it + 1);
+    KB_MARK(6);                                    // S(it + 1): wait for R / Z, sd, split, LDS writes, arrive
+    fetch_rz(it + 2);
+    fetch_attn(it + 2, ax);
+    __builtin_amdgcn_sched_barrier(0);
+    KB_MARK(0);                                    // requests
+    if (it < ntiles) {                             // (the pair loop runs one tile beyond an odd tile count: no products there)
+      // ---- row side: G = S v^T for this wave's key block ----
+      f32x16 gacc;
+      zero16(gacc);
+      {
+        const unsigned char* Ab = Sc + lr * kRLD + 16 * kh;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          bf16x8 a[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(Ab + q * kPlR + 32 * s4);
+          mfma_x6(gacc, a, vpl[s4]);
+        }
+      }
+      KB_MARK(1);                                  // row product issued
+      // ---- the N x N result of this tile: cam_attn = attn . G straight from the accumulators, to rows through LDS, stored as
+      // 16-byte pieces (full key blocks), else dword stores masked by key ----
+      float gp[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gp[e] = (MODE == RULE) ? (ac[e] * gacc[e]) * scale : gacc[e];
+      const unsigned base = (unsigned)(it * TI) * row_bytes;
+      if (blk_full) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Xb[crow(e, kh) * XLD + lr] = gp[e];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(Xb + (8 * p + xr) * XLD + xc);
+          st128_hidden(t, ca_rs, lane_x4 + (base + (unsigned)(8 * p) * row_bytes));
+        }
+      } else if (key_ok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st32_hidden(gp[e], ca_rs, lane_nn + (base + (unsigned)((e & 3) + 8 * (e >> 2)) * row_bytes));
+      }
+      KB_MARK(3);                                  // result formed, staged, stored
+      // ---- column side: cam_v += attn^T S (keys x 64); K step s = rows crow(8 s .. 8 s + 7, kh) ----
+      bf16x8 apl[2][3];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float x[8] = {ac[8 * s2], ac[8 * s2 + 1], ac[8 * s2 + 2], ac[8 * s2 + 3],
+                            ac[8 * s2 + 4], ac[8 * s2 + 5], ac[8 * s2 + 6], ac[8 * s2 + 7]};
+        split3_x8(x, apl[s2]);
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const unsigned char* Bb = Sc + 3 * kPlR + (db * 32 + lr) * kTLD + 16 * kh;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 bq[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const bf16x8*>(Bb + q * kPlT + 32 * s2);
+          mfma_x6(accv[db], apl[s2], bq);
+        }
+      }
+    }
+    KB_MARK(2);                                    // attn split + column product issued
+    // attn(it + 1) was requested a tile ago; younger loads in flight: R / Z(it + 2) and attn(it + 2) of this tile
+    if constexpr (kRz == 2) TE_VM_WAIT(6);
+    else TE_VM_WAIT(5);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) TE_PIN(ay[p]);
+    to_acc(ay, ac);                                // the next tile's attn block (the staging block is free: its rows were read)
+  };
+  KB_MARK(7);
+#pragma unroll 1
+  for (int it = 0; it < ntiles; it += 2) {
+    tile(it, an2, an);
+    tile(it + 1, an, an2);
+  }
+  TE_VM_WAIT(0);                                   // (requests beyond the last tile: zeros, but their registers are in flight)
+
+  // ---- column epilogue: accv[db][e] = (attn^T S)[key = 32 kb + crow(e, kh)][d = 32 db + lr]; keys beyond N: dropped ----
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const unsigned d4 = (unsigned)(db * 32 + lr) * 4u;
+    float x[16];
+    if constexpr (MODE == RULE) {
+      const unsigned xoff = (unsigned)(kb * 32 + 4 * kh) * (unsigned)vs.sn * 4u + d4;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] = ld32(v_rs, xoff + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)vs.sn * 4u);
+    }
+    const unsigned ooff = (unsigned)(kb * 32 + 4 * kh) * (unsigned)cs.sn * 4u + d4;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float val = accv[db][e];
+      if constexpr (MODE == RULE) val = (x[e] * val) * scale;
+      st32(val, cv_rs, ooff + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)cs.sn * 4u);
+    }
+  }
+#ifdef TE_STUDY
+  if constexpr (PROF) {
+    KB_MARK(7);
+    if (blockIdx.x == 0 && lane == 0)
+      for (int q = 0; q < 8; ++q) g_kb_prof[wave * 8 + q] = prof_acc[q];
+  }
+#endif
+}
+
 // key blocks per workgroup: at most eight (one per wave), the blocks of a (b, h) spread evenly over ceil(nkb / 8) workgroups
 inline void groups_for(int64_t N, int& ng, int& kbg) {
   const int nkb = (int)((N + 31) / 32);
@@ -446,17 +754,39 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
     TE_KB_ST(1) TE_KB_ST(2) TE_KB_ST(4) TE_KB_ST(5) TE_KB_ST(8) TE_KB_ST(9)
 #undef TE_KB_ST
     const char* e = getenv("TE_ATTN_KB_PROF");
-    if (e && atoi(e) == 1) {
+    const char* av = getenv("TE_ATTN_AV");
+    if (e && atoi(e) == 1 && av && !strcmp(av, "fp32kb")) {
       av_kb_kernel<RULE, true><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
       return TE_OK;
     }
   }
 #endif
+  bool fp32 = false;
+#ifdef TE_STUDY
+  if (const char* e = getenv("TE_ATTN_AV")) fp32 = !strcmp(e, "fp32kb");
+#endif
+  if (fp32) {
+    if (mode == 0)
+      av_kb_kernel<RULE><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
+    else
+      av_kb_kernel<BWD><<<grid, blk, 0, stream>>>(R, rs, nullptr, Strided{0, 0, 0}, attn, v, vs, cam_attn, cam_v, cs, (int)H,
+                                                  (int)N, BH, kbg, 1.0f);
+    return TE_OK;
+  }
+#ifdef TE_STUDY
+  if (mode == 0) {
+    const char* e = getenv("TE_ATTN_KB_PROF");
+    if (e && atoi(e) == 1) {
+      av6_kb_kernel<RULE, true><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
+      return TE_OK;
+    }
+  }
+#endif
   if (mode == 0)
-    av_kb_kernel<RULE><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
+    av6_kb_kernel<RULE><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
   else
-    av_kb_kernel<BWD><<<grid, blk, 0, stream>>>(R, rs, nullptr, Strided{0, 0, 0}, attn, v, vs, cam_attn, cam_v, cs, (int)H,
-                                                (int)N, BH, kbg, 1.0f);
+    av6_kb_kernel<BWD><<<grid, blk, 0, stream>>>(R, rs, nullptr, Strided{0, 0, 0}, attn, v, vs, cam_attn, cam_v, cs, (int)H,
+                                                 (int)N, BH, kbg, 1.0f);
   return TE_OK;
 }
 
