@@ -92,7 +92,10 @@ __device__ __forceinline__ f32x4 ld128_hidden(Rsrc r, unsigned voff) {
 #define TE_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define TE_PIN(v) asm volatile("" : "+v"(v))
 __device__ __forceinline__ void st128_hidden(f32x4 x, Rsrc r, unsigned voff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(x), "v"(voff), "s"(r));
+  // (s_nop: a store of more than 64 bits reads the upper half of its data one cycle late -- the VALU instruction that follows
+  //  must not write those registers.  hipcc pads this hazard for its own stores, not for inline asm: without the wait state
+  //  cam_q came back with the upper 8 bytes of some lanes' 16-byte pieces replaced by whatever was written next, sporadically)
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(x), "v"(voff), "s"(r));
 }
 __device__ __forceinline__ void st32_hidden(float x, Rsrc r, unsigned voff) {
   asm volatile("buffer_store_dword %0, %1, %2, 0 offen" : : "v"(x), "v"(voff), "s"(r));
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(kT) void av_kb_kernel(
     // __syncthreads()) into s_waitcnt vmcnt(0), i.e. a full drain of the wave's global-memory pipeline at every tile: the
     // prefetches just issued, two tiles ahead, and the stores (found in the ISA after the phase profile showed every wave
     // waiting ~2 500 cycles where it forms S: with the drain the kernel's time was memory time PLUS MFMA time)
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's LDS writes have been PERFORMED before it arrives: a
+                                                            // later single-lane atomic can overtake the tail of a 64-lane write
     if (lane == 0) __hip_atomic_fetch_add(&arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto wait_s = [&](int it) __attribute__((always_inline)) {            // S(it) complete
@@ -531,7 +535,8 @@ __global__ __launch_bounds__(kT) void av6_kb_kernel(
       *reinterpret_cast<unsigned short*>(t + 2 * kTLD) = (unsigned short)(p23[q] & 0xffffu);
       *reinterpret_cast<unsigned short*>(t + 3 * kTLD) = (unsigned short)(p23[q] >> 16);
     }
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's LDS writes have been PERFORMED before it arrives: a
+                                                            // later single-lane atomic can overtake the tail of a 64-lane write
     if (lane == 0) __hip_atomic_fetch_add(&arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto wait_s = [&](int it) __attribute__((always_inline)) {            // S(it) complete
@@ -719,6 +724,304 @@ __global__ __launch_bounds__(kT) void av6_kb_kernel(
 #endif
 }
 
+// ================================================================================================
+// QK rule on the same machinery (einsum 'bhid,bhjd->bhij', layers_ours.py:48-60,122-127; ViT_LRP.py:165-173, BERT.py:386-393):
+//   S = sd(R f, Z) [N,N];  cam_q = q . (S k) * scale;  cam_k = k . (S^T q) * scale          (f: the deferred factor of BERT's mask Add)
+// R, Z contiguous [B*H,N,N]; q, k, cam_q, cam_k strided [B,H,N,64].  Wave w owns key block kb: its [32 rows x 32 keys] blocks of
+// R and Z arrive as 16-byte pieces, change to the accumulator layout through LDS, S is formed in registers and is
+//   - split along the ROWS (K of the column product cam_k += S^T q: A operand; B = the q tile's planes, transposed image in LDS),
+//   - staged as rows and split along the KEYS (K of the row product  S k  over the wave's 32 keys: A operand; B = the planes of
+//     k^T of the wave's keys, resident in 48 registers).
+// The row product of a wave is a PARTIAL sum over its 32 keys: the partials meet in LDS (one [32][64] fp32 slab per wave) and
+// every thread folds its four outputs over the waves in wave order -- an order that depends on N only.  Three LDS counters
+// order the exchange (q planes produced / partials written / partials read); no barrier.  More than eight key blocks
+// (N > 256): each workgroup of a (b, h) writes its unscaled partial of cam_q to `qpart`, folded by qk_finish_kernel in group order.
+// ================================================================================================
+constexpr int PLD = 68;                    // row stride (floats) of a wave's partial slab [32 rows][64 d]
+
+template <int MODE, bool PROF = false>
+__global__ __launch_bounds__(kT) void qk6_kb_kernel(
+    const float* __restrict__ Rnn, const float* __restrict__ Znn, const float* __restrict__ q, Strided qs,
+    const float* __restrict__ k, Strided ks, float* __restrict__ cam_q, Strided cqs, float* __restrict__ cam_k, Strided cks,
+    float* __restrict__ qpart, int H, int N, int BH, int KBG, int ngroups, float scale, const float* __restrict__ r_scale,
+    int64_t r_scale_stride) {
+  static_assert(MODE == RULE, "the softmax-backward mode runs on te_attn_rules.hip's kernel");
+  __shared__ __attribute__((aligned(16))) unsigned char Qb[3][3 * kPlT];    // q tile k lives in buffer k % 3: transposed planes
+  __shared__ __attribute__((aligned(16))) float Xw[kWaves][TI * XLD];      // wave-private: layout changes
+  __shared__ __attribute__((aligned(16))) float Pred[kWaves][TI * PLD];    // per-wave partials of the row product
+  __shared__ unsigned cnt[4];                                              // [0] q planes  [1] partials written  [2] read
+  if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int bh = blockIdx.x % BH, g = blockIdx.x / BH;
+  const int b = bh / H, h = bh - b * H;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, kh = lane >> 5;
+  long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = PROF ? clock64() : 0;
+  (void)prof_acc;
+  const int nkb = (N + 31) >> 5, kb = g * KBG + wave;
+  const bool has_blk = wave < KBG && kb < nkb;            // wave-uniform
+  const int nwb = min(KBG, nkb - g * KBG);                // waves of this workgroup that own a key block
+  const int j = kb * 32 + lr;
+  const int ntiles = (N + TI - 1) / TI;
+  const int niter = (ntiles + 1) & ~1;                    // the pair loop's trip count (one tile beyond an odd count: zeros)
+  const int srow = threadIdx.x >> 4, sc = threadIdx.x & 15;
+  const int spos = (srow & 0x13) | ((srow & 4) << 1) | ((srow & 8) >> 1);
+  const float f = r_scale ? r_scale[(int64_t)b * r_scale_stride] : 1.0f;
+
+  const unsigned nn_bytes = (unsigned)N * (unsigned)N * 4u;
+  const Rsrc r_rs = make_rsrc(Rnn + (int64_t)bh * N * N, nn_bytes);
+  const Rsrc z_rs = make_rsrc(Znn + (int64_t)bh * N * N, nn_bytes);
+  const Rsrc q_rs = make_rsrc(q + (int64_t)b * qs.sb + (int64_t)h * qs.sh, view_bytes(N, qs.sn));
+  const Rsrc k_rs = make_rsrc(k + (int64_t)b * ks.sb + (int64_t)h * ks.sh, view_bytes(N, ks.sn));
+  const Rsrc cq_rs = (ngroups == 1) ? make_rsrc(cam_q + (int64_t)b * cqs.sb + (int64_t)h * cqs.sh, view_bytes(N, cqs.sn))
+                                    : make_rsrc(qpart + ((int64_t)g * BH + bh) * N * 64, (unsigned)N * 256u);
+  const unsigned cq_row = (ngroups == 1) ? (unsigned)cqs.sn * 4u : 256u;
+  const Rsrc ck_rs = make_rsrc(cam_k + (int64_t)b * cks.sb + (int64_t)h * cks.sh, view_bytes(N, cks.sn));
+  const unsigned row_bytes = (unsigned)N * 4u;
+
+  auto arrive = [&](int c) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's LDS writes have been PERFORMED before it arrives: a
+                                                            // later single-lane atomic can overtake the tail of a 64-lane write
+    if (lane == 0) __hip_atomic_fetch_add(&cnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_for = [&](int c, unsigned target) __attribute__((always_inline)) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+
+  // ---- the q tile: every thread one float4; q(it) -> transposed planes of buffer it % 3 (B operand of the column product) ----
+  f32x4 qq = {0.f, 0.f, 0.f, 0.f}, qcur = {0.f, 0.f, 0.f, 0.f};       // qq: in flight / just landed; qcur: this tile's (for cam_q)
+  const unsigned q_off = ((unsigned)srow * (unsigned)qs.sn + 4u * sc) * 4u, q_tile = (unsigned)TI * (unsigned)qs.sn * 4u;
+  auto fetch_q = [&](int it) __attribute__((always_inline)) { qq = ld128_hidden(q_rs, q_off + (unsigned)it * q_tile); };
+  auto put_q = [&](int it) __attribute__((always_inline)) {            // (rows beyond N: zeros)
+    unsigned p01[3], p23[3];
+    split3_pk(qq[0], qq[1], p01);
+    split3_pk(qq[2], qq[3], p23);
+    unsigned char* base = Qb[it % 3];
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      unsigned char* t = base + pq * kPlT + (4 * sc) * kTLD + spos * 2;
+      *reinterpret_cast<unsigned short*>(t) = (unsigned short)(p01[pq] & 0xffffu);
+      *reinterpret_cast<unsigned short*>(t + kTLD) = (unsigned short)(p01[pq] >> 16);
+      *reinterpret_cast<unsigned short*>(t + 2 * kTLD) = (unsigned short)(p23[pq] & 0xffffu);
+      *reinterpret_cast<unsigned short*>(t + 3 * kTLD) = (unsigned short)(p23[pq] >> 16);
+    }
+    arrive(0);
+  };
+  // ---- fold the partials of tile `it` (this thread: row srow, features 4 sc .. + 3), in wave order ----
+  auto reduce_tile = [&](int it) __attribute__((always_inline)) {
+    wait_for(1, (unsigned)nwb * (unsigned)(it + 1));
+    f32x4 sum = *reinterpret_cast<const f32x4*>(&Pred[0][srow * PLD + 4 * sc]);
+    for (int w = 1; w < nwb; ++w) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(&Pred[w][srow * PLD + 4 * sc]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] = sum[e] + t[e];
+    }
+    arrive(2);
+    if (ngroups == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] = (qcur[e] * sum[e]) * scale;
+    }
+    st128_hidden(sum, cq_rs, ((unsigned)(it * TI + srow) * cq_row) + 16u * sc);      // rows beyond N: dropped
+  };
+
+  if (!has_blk) {
+    // a wave without a key block: forms its part of the q planes and folds its share of the partials
+    fetch_q(0);
+    TE_VM_WAIT(0);
+    TE_PIN(qq);
+    put_q(0);
+    qcur = qq;
+    fetch_q(1);
+    for (int it = 0; it < niter; ++it) {
+      wait_for(0, (unsigned)kWaves * (unsigned)(it + 1));      // (throttle: q(it + 1) overwrites q(it - 2))
+      TE_VM_WAIT(0);
+      TE_PIN(qq);
+      put_q(it + 1);
+      const f32x4 qnext = qq;
+      fetch_q(it + 2);
+      reduce_tile(it);
+      qcur = qnext;
+    }
+    TE_VM_WAIT(0);
+    return;
+  }
+
+  // B operand of the row product, resident: the planes of k[16 s + 8 kh + 0..7][32 db + lr] of the wave's 32 keys
+  bf16x8 kpl[2][2][3];
+  {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          x[i] = ld32(k_rs, ((unsigned)(kb * 32 + 16 * s2 + 8 * kh + i) * (unsigned)ks.sn + (unsigned)(db * 32 + lr)) * 4u);
+        split3_x8(x, kpl[db][s2]);
+      }
+  }
+  float* const Xb = Xw[wave];
+  const int xr = lane >> 3, xc = (lane & 7) << 2;
+  const unsigned lane_x4 = ((unsigned)xr * (unsigned)N + (unsigned)(kb * 32 + xc)) * 4u;
+  auto fetch_nn = [&](Rsrc rs_, int it, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+    const unsigned base = (unsigned)(it * TI) * row_bytes;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dst[p] = ld128_hidden(rs_, lane_x4 + (base + (unsigned)(8 * p) * row_bytes));
+  };
+  auto to_acc = [&](const f32x4 (&src)[4], float (&dst)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(Xb + (8 * p + xr) * XLD + xc) = src[p];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst[e] = Xb[crow(e, kh) * XLD + lr];
+  };
+
+  float rc[16], zc[16];                            // this tile's R and Z blocks, accumulator layout
+  f32x4 ra[4], za[4], rb[4], zb[4];                // two register sets for the blocks in flight
+  fetch_q(0);
+  fetch_nn(r_rs, 0, rb);
+  fetch_nn(z_rs, 0, zb);
+  TE_VM_WAIT(0);                                   // (prologue: hipcc's own loads of k above included)
+  TE_PIN(qq);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int pq = 0; pq < 3; ++pq) TE_PIN(kpl[db][s2][pq]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    TE_PIN(rb[p]);
+    TE_PIN(zb[p]);
+  }
+  put_q(0);
+  qcur = qq;
+  fetch_q(1);
+  fetch_nn(r_rs, 1, ra);
+  fetch_nn(z_rs, 1, za);
+  to_acc(rb, rc);
+  to_acc(zb, zc);
+  // In flight when the loop starts, oldest first: q(1), R(1), Z(1).  Every iteration issues q(it + 2), R(it + 2), Z(it + 2) at
+  // its top and the store of its share of cam_q at its end.
+
+  f32x16 acck[2];
+  zero16(acck[0]);
+  zero16(acck[1]);
+  // (rx / zx: the sets tile it + 2 is requested into, ry / zy: the sets holding tile it + 1)
+  auto tile = [&](int it, f32x4 (&rx)[4], f32x4 (&zx)[4], f32x4 (&ry)[4], f32x4 (&zy)[4]) __attribute__((always_inline)) {
+    const unsigned char* Qc = Qb[it % 3];
+    wait_for(0, (unsigned)kWaves * (unsigned)(it + 1));      // the q planes of tile it
+    TE_VM_WAIT(8);                                 // q(it + 1): younger loads in flight = R(it + 1), Z(it + 1)
+    TE_PIN(qq);
+    put_q(it + 1);
+    const f32x4 qnext = qq;
+    fetch_q(it + 2);
+    fetch_nn(r_rs, it + 2, rx);
+    fetch_nn(z_rs, it + 2, zx);
+    __builtin_amdgcn_sched_barrier(0);
+    KB_MARK(0);                                    // poll q, wait, q planes, requests
+    // ---- S = sd(R f, Z) in the accumulator layout (rows / keys beyond N: sd(0, 0) = 0) ----
+    float sv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sv[e] = te_sd(rc[e] * f, zc[e]);
+    // rows of S for the row product (staged before the column product: its LDS round trip hides under those MFMAs)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Xb[crow(e, kh) * XLD + lr] = sv[e];
+    KB_MARK(1);                                    // sd, S rows staged
+    // ---- column side: cam_k += S^T q (keys x 64); K step s = rows crow(8 s .. 8 s + 7, kh) ----
+    {
+      bf16x8 spl[2][3];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float x[8] = {sv[8 * s2], sv[8 * s2 + 1], sv[8 * s2 + 2], sv[8 * s2 + 3],
+                            sv[8 * s2 + 4], sv[8 * s2 + 5], sv[8 * s2 + 6], sv[8 * s2 + 7]};
+        split3_x8(x, spl[s2]);
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const unsigned char* Bb = Qc + (db * 32 + lr) * kTLD + 16 * kh;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 bq[3];
+#pragma unroll
+          for (int pq = 0; pq < 3; ++pq) bq[pq] = *reinterpret_cast<const bf16x8*>(Bb + pq * kPlT + 32 * s2);
+          mfma_x6(acck[db], spl[s2], bq);
+        }
+      }
+    }
+    KB_MARK(2);                                    // split + column product
+    // ---- row side, this wave's 32 keys: P = S k; K step s = keys 16 s + 8 kh + 0..7 ----
+    f32x16 pacc[2];
+    zero16(pacc[0]);
+    zero16(pacc[1]);
+    {
+      bf16x8 rpl[2][3];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Xb + lr * XLD + 16 * s2 + 8 * kh);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Xb + lr * XLD + 16 * s2 + 8 * kh + 4);
+        const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        split3_x8(x, rpl[s2]);
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) mfma_x6(pacc[db], rpl[s2], kpl[db][s2]);
+    }
+    KB_MARK(3);                                    // rows, split, row product
+    // ---- the partials meet: wait until the previous tile's have been read, publish, fold this thread's outputs ----
+    wait_for(2, (unsigned)kWaves * (unsigned)it);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Pred[wave][crow(e, kh) * PLD + db * 32 + lr] = pacc[db][e];
+    arrive(1);
+    KB_MARK(4);                                    // wait for the readers of the previous tile, publish
+    reduce_tile(it);
+    qcur = qnext;
+    KB_MARK(5);                                    // wait for the partials, fold, store
+    // R / Z(it + 1) were requested a tile ago; younger loads in flight: q, R, Z of tile it + 2
+    TE_VM_WAIT(9);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      TE_PIN(ry[p]);
+      TE_PIN(zy[p]);
+    }
+    to_acc(ry, rc);
+    to_acc(zy, zc);
+    KB_MARK(6);                                    // wait for R / Z of the next tile, change of layout
+  };
+  KB_MARK(7);
+#pragma unroll 1
+  for (int it = 0; it < niter; it += 2) {
+    tile(it, rb, zb, ra, za);
+    tile(it + 1, ra, za, rb, zb);
+  }
+  TE_VM_WAIT(0);
+
+  // ---- column epilogue: acck[db][e] = (S^T q)[key = 32 kb + crow(e, kh)][d = 32 db + lr]; keys beyond N: dropped ----
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const unsigned d4 = (unsigned)(db * 32 + lr) * 4u;
+    float x[16];
+    const unsigned xoff = (unsigned)(kb * 32 + 4 * kh) * (unsigned)ks.sn * 4u + d4;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = ld32(k_rs, xoff + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)ks.sn * 4u);
+    const unsigned ooff = (unsigned)(kb * 32 + 4 * kh) * (unsigned)cks.sn * 4u + d4;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      st32((x[e] * acck[db][e]) * scale, ck_rs, ooff + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)cks.sn * 4u);
+  }
+#ifdef TE_STUDY
+  if constexpr (PROF) {
+    KB_MARK(7);
+    if (blockIdx.x == 0 && lane == 0)
+      for (int qi = 0; qi < 8; ++qi) g_kb_prof[wave * 8 + qi] = prof_acc[qi];
+  }
+#endif
+}
+
 // key blocks per workgroup: at most eight (one per wave), the blocks of a (b, h) spread evenly over ceil(nkb / 8) workgroups
 inline void groups_for(int64_t N, int& ng, int& kbg) {
   const int nkb = (int)((N + 31) / 32);
@@ -787,6 +1090,35 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
   else
     av6_kb_kernel<BWD><<<grid, blk, 0, stream>>>(R, rs, nullptr, Strided{0, 0, 0}, attn, v, vs, cam_attn, cam_v, cs, (int)H,
                                                  (int)N, BH, kbg, 1.0f);
+  return TE_OK;
+}
+
+// the QK rule; *ngroups_out = workgroups per (b, h): with more than one, cam_q's per-group partials are in qpart
+// [ngroups][B*H][N][64] (unscaled) and the caller runs its finishing kernel
+int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
+              int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
+              float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
+              float* qpart, const float* r_scale, int64_t r_scale_stride, int* ngroups_out, hipStream_t stream) {
+  int ng, kbg;
+  groups_for(N, ng, kbg);
+  *ngroups_out = ng;
+  const int BH = (int)(B * H);
+  if (q_sn > 65536 || k_sn > 65536 || cq_sn > 65536 || ck_sn > 65536) return TE_ERR_UNSUPPORTED;
+  const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
+#ifdef TE_STUDY
+  {
+    const char* e = getenv("TE_ATTN_KB_PROF");
+    if (e && atoi(e) == 2) {
+      qk6_kb_kernel<RULE, true><<<dim3((unsigned)(BH * ng)), dim3(kT), 0, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k, cks,
+                                                                                  qpart, (int)H, (int)N, BH, kbg, ng, scale,
+                                                                                  r_scale, r_scale_stride);
+      return TE_OK;
+    }
+  }
+#endif
+  qk6_kb_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), 0, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k, cks, qpart,
+                                                                        (int)H, (int)N, BH, kbg, ng, scale, r_scale,
+                                                                        r_scale_stride);
   return TE_OK;
 }
 

@@ -53,6 +53,10 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
               int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* Z, int64_t z_sb, int64_t z_sh, int64_t z_sn,
               float* cam_attn, float* cam_v, int64_t cv_sb, int64_t cv_sh, int64_t cv_sn, int64_t B, int64_t H, int64_t N,
               float scale, hipStream_t stream);
+int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
+              int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
+              float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
+              float* qpart, const float* r_scale, int64_t r_scale_stride, int* ngroups_out, hipStream_t stream);
 }  // namespace te_attn_kb
 
 namespace te_attn_rules {
@@ -917,6 +921,18 @@ static bool use_kb_av() {
 #endif
 }
 
+static bool use_kb_qk() {       // TE_ATTN_QK=old (measurement builds): the round-2 QK rule kernel
+#ifdef TE_STUDY
+  static const bool on = [] {
+    const char* e = getenv("TE_ATTN_QK");
+    return !(e && !strcmp(e, "old"));
+  }();
+  return on;
+#else
+  return true;
+#endif
+}
+
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   int ng, jg;
   groups_for(N, ng, jg);
@@ -950,6 +966,19 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
   if (q_sn > 65536) return TE_ERR_UNSUPPORTED;                       // 32-bit row offsets inside a (b, h) view
+  if (use_kb_qk() && te_attn_kb::supported(B, H, N, 64)) {
+    const Strided qs{q_sb, q_sh, q_sn}, cqs{cq_sb, cq_sh, cq_sn};
+    int kng = 1;
+    int rc = te_attn_kb::qk_launch(Rnn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn, cam_k, ck_sb,
+                                   ck_sh, ck_sn, B, H, N, scale, qpart, r_scale, r_scale_stride, &kng, stream);
+    if (rc != TE_OK) return rc;
+    if (kng > 1) {
+      const int64_t n4 = (int64_t)BH * N * 16;
+      qk_finish_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream>>>(qpart, q, qs, cam_q, cqs, (int)H, (int)N,
+                                                                                    BH, kng, scale);
+    }
+    return TE_OK;
+  }
   allow_lds(qk_rule_kernel<RULE>, lds_qk(256, false));
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
   qk_rule_kernel<RULE><<<dim3((unsigned)(BH * ng)), dim3(kT), lds_qk(jg, false), stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k,
