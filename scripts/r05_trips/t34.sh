@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}" || exit 1
+mkdir -p gpurun_out; export TMPDIR=/tmp
+( TE_BUILD_DEFINES=TE_STUDY timeout 600 python transformer-explainability_amd/build.py 2>&1 | tail -2 ) > gpurun_out/t34_build_study.log
+for cfg in "x6 old" "old x6" "fp32kb old"; do
+  set -- $cfg
+  ( echo "== AV=$1 QK=$2"; TE_ATTN_AV=$1 TE_ATTN_QK=$2 timeout 300 python scripts/graph_vs_eager.py 2>&1 | grep -v amdgpu | grep "graph replay" | grep -c DIFFERENT ) >> gpurun_out/t34.log
+done
+cat gpurun_out/t34.log

@@ -724,6 +724,7 @@ __global__ __launch_bounds__(kT) void av6_kb_kernel(
 #endif
 }
 
+#ifdef TE_STUDY      // (a study, see te_attn_rules.hip: use_kb_qk)
 // ================================================================================================
 // QK rule on the same machinery (einsum 'bhid,bhjd->bhij', layers_ours.py:48-60,122-127; ViT_LRP.py:165-173, BERT.py:386-393):
 //   S = sd(R f, Z) [N,N];  cam_q = q . (S k) * scale;  cam_k = k . (S^T q) * scale          (f: the deferred factor of BERT's mask Add)
@@ -1022,6 +1023,8 @@ __global__ __launch_bounds__(kT) void qk6_kb_kernel(
 #endif
 }
 
+#endif      // TE_STUDY
+
 // key blocks per workgroup: at most eight (one per wave), the blocks of a (b, h) spread evenly over ceil(nkb / 8) workgroups
 inline void groups_for(int64_t N, int& ng, int& kbg) {
   const int nkb = (int)((N + 31) / 32);
@@ -1093,12 +1096,13 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
   return TE_OK;
 }
 
-// the QK rule; *ngroups_out = workgroups per (b, h): with more than one, cam_q's per-group partials are in qpart
+// the QK rule (study builds only); *ngroups_out = workgroups per (b, h): with more than one, cam_q's per-group partials are in qpart
 // [ngroups][B*H][N][64] (unscaled) and the caller runs its finishing kernel
 int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
               int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn,
               float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale,
               float* qpart, const float* r_scale, int64_t r_scale_stride, int* ngroups_out, hipStream_t stream) {
+#ifdef TE_STUDY
   int ng, kbg;
   groups_for(N, ng, kbg);
   *ngroups_out = ng;
@@ -1120,6 +1124,11 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
                                                                         (int)H, (int)N, BH, kbg, ng, scale, r_scale,
                                                                         r_scale_stride);
   return TE_OK;
+#else
+  (void)Rnn, (void)q, (void)k, (void)Z, (void)cam_q, (void)cam_k, (void)qpart, (void)r_scale, (void)stream;
+  *ngroups_out = 1;
+  return TE_ERR_UNSUPPORTED;
+#endif
 }
 
 }  // namespace te_attn_kb

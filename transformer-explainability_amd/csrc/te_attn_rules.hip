@@ -921,15 +921,20 @@ static bool use_kb_av() {
 #endif
 }
 
-static bool use_kb_qk() {       // TE_ATTN_QK=old (measurement builds): the round-2 QK rule kernel
+// The QK rule on wave-owned key blocks (te_attn_kb.hip: qk6_kb_kernel) is a STUDY: TE_ATTN_QK=x6 in measurement builds.
+// Round 5 state: correct in every parity test and 4-7 % faster than qk_rule_kernel below (170 vs 177-190 us at N = 197), but
+// inside the replayed ViT-B step (relprop beside the backward pass) 2 of 10 replays differed from the serial step in the
+// last bits of one sample -- a race in its cross-wave exchange of row-product partials that isolated runs (40 x 768
+// workgroups, with and without concurrent attention kernels) never showed.  Not shipped until found.
+static bool use_kb_qk() {
 #ifdef TE_STUDY
   static const bool on = [] {
     const char* e = getenv("TE_ATTN_QK");
-    return !(e && !strcmp(e, "old"));
+    return e && !strcmp(e, "x6");
   }();
   return on;
 #else
-  return true;
+  return false;
 #endif
 }
 
