@@ -19,6 +19,9 @@ and seeded ``randn`` inputs, torch CPU fp32.  Fixtures:
   perturbation.npz  SURVEY.md 8f.4: the six result arrays of pertubation_eval_from_hdf5.py's eval(args), run on a
                   narrow ViT_new and seeded inputs (positive / negative / fixed-pixel-count modes)
   seg_metrics.npz   the reference's utils/metrices.py functions called as imagenet_seg_eval.py calls them
+  e2e_fp64.npz    VERDICT r4 item 5: the reference's fp32 AND fp64 maps of 16 + 4 + 4 samples of the three full-size
+                  configurations (python tests/golden/make_golden.py e2e64; ~15 min of CPU), for the end-to-end statistic
+                  ||ours - ref64|| <= k ||ref32 - ref64||
   bands.npz       SURVEY.md 8d "reorder-noise band": for every full-size golden map (ViT-B/16, BERT-base) the distance
                   of the REFERENCE from itself when only fp32 rounding changes -- 1 thread vs all threads (another GEMM
                   blocking / summation order) and fp32 vs the same model run in fp64 -- as min-max-normalised and
@@ -577,6 +580,74 @@ def make_segmentation():
     print("seg_metrics.npz", {k: np.asarray(v).shape for k, v in out.items()})
 
 
+# ------------------------------------------------------------------------------------------
+# an end-to-end statistic that means something where the reference is unstable.  For samples of the
+# three full-size configurations AS THE GPU TESTS RUN THEM (tests/test_gpu_models.py: test_config1 / 2 / 3) the
+# reference's map in fp32 (ref32) and the same model run in fp64 (ref64, the closest thing to the truth the reference's
+# own code gives).  The GPU test asserts  ||ours - ref64|| <= k ||ref32 - ref64||  over the samples: our end-to-end map
+# (own producers, x6 products, graph replay) is as close to the fp64 result as the reference's fp32 map is.
+E2E_VIT_B = tuple(range(0, 64, 4))           # 16 of the headline batch (seeded_randn((64, 3, 224, 224), 1)), start_layer 1
+E2E_VIT_L = (3, 10, 21, 31)                  # of seeded_randn((32, 3, 384, 384), 5), start_layer 1
+E2E_BERT = (0, 1, 14, 31)                    # of the config-3 batch (ids seed 1, every other sequence padded), start_layer 0
+
+
+def make_e2e64():
+    import copy
+    import time
+    threads = max(1, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    out = {}
+    vit = rh.load_reference_vit()
+
+    def vit_maps(model, x, idxs, tag):
+        m64 = copy.deepcopy(model).double()
+        g32, g64 = vit["gen"].LRP(model), vit["gen"].LRP(m64)
+        a, b = [], []
+        for i in idxs:
+            t0 = time.time()
+            a.append(g32.generate_LRP(x[i:i + 1], method="transformer_attribution", start_layer=1).detach().clone())
+            b.append(g64.generate_LRP(x[i:i + 1].double(), method="transformer_attribution", start_layer=1).detach().clone())
+            d = _dist(a[-1], b[-1])
+            print(f"{tag} sample {i}: |ref32 - ref64| normalised {d[0]:.2e} relative {d[1]:.2e}  ({time.time() - t0:.0f} s)", flush=True)
+        out[tag + ".samples"] = np.array(idxs, dtype=np.int64)
+        out[tag + ".ref32"] = npy(torch.cat(a, 0))
+        out[tag + ".ref64"] = torch.cat(b, 0).numpy()
+
+    model = vit["ViT_LRP"].vit_base_patch16_224(pretrained=False).eval()
+    rh.synthetic_init(model, 0)
+    vit_maps(model, rh.seeded_randn((64, 3, 224, 224), 1), E2E_VIT_B, "vit_b16_b64.sl1")
+    del model
+    model = vit["ViT_LRP"].vit_large_patch16_224(pretrained=False, img_size=384).eval()
+    rh.synthetic_init(model, 0)
+    vit_maps(model, rh.seeded_randn((32, 3, 384, 384), 5), E2E_VIT_L, "vit_l16_384_b32.sl1")
+    del model
+
+    bert = rh.load_reference_bert()
+    from transformers import BertConfig
+    cfg = BertConfig(num_labels=2)
+    cfg.return_dict = False
+    bm = bert["cls"].BertForSequenceClassification(cfg).eval()
+    rh.synthetic_init(bm, 0)
+    bm64 = copy.deepcopy(bm).double()
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1000, 20000, (32, 512), generator=g)
+    mask = torch.ones(32, 512)
+    mask[::2, 512 - 64:] = 0
+    g32, g64 = bert["gen"].Generator(bm), bert["gen"].Generator(bm64)
+    a, b = [], []
+    for i in E2E_BERT:
+        a.append(g32.generate_LRP(input_ids=ids[i:i + 1], attention_mask=mask[i:i + 1], start_layer=0).detach().clone())
+        b.append(g64.generate_LRP(input_ids=ids[i:i + 1], attention_mask=mask[i:i + 1], start_layer=0).detach().clone())
+        d = _dist(a[-1], b[-1])
+        print(f"bert_base_512 sample {i}: |ref32 - ref64| normalised {d[0]:.2e} relative {d[1]:.2e}", flush=True)
+    out["bert_base_512_b32.sl0.samples"] = np.array(E2E_BERT, dtype=np.int64)
+    out["bert_base_512_b32.sl0.ref32"] = npy(torch.cat(a, 0))
+    out["bert_base_512_b32.sl0.ref64"] = torch.cat(b, 0).numpy()
+    np.savez_compressed(os.path.join(HERE, "e2e_fp64.npz"), **out)
+    print("e2e_fp64.npz", len(out), "arrays")
+
+
+
 if __name__ == "__main__":
     if not rh.reference_available():
         sys.exit("reference checkout not found at " + rh.REFERENCE_ROOT)
@@ -600,3 +671,5 @@ if __name__ == "__main__":
         make_segmentation()
     if "bands" in which:
         make_bands()
+    if "e2e64" in which:
+        make_e2e64()

@@ -95,6 +95,51 @@ def _assert_map(name, got, ref, norm_tol=NORM_TOL, rel_tol=REL_TOL):
     return s
 
 
+# ------------------------------------------------------------------------------------------ end to end vs the fp64 reference
+def _e2e_vs_fp64(name, ours, prefix, k_median, k_each=50.0):
+    """VERDICT r4 item 5.  tests/golden/e2e_fp64.npz holds, for samples of this configuration exactly as this test feeds
+    them, the reference's own map in fp32 (ref32) and the same reference model run in fp64 (ref64) -- CPU, the unmodified
+    reference code (make_golden.py e2e64).  LRP divides by mixed-sign sums near zero: at start_layer = 1 the reference's
+    fp32 map does not reproduce ITSELF to 1e-4 (bands.npz), so "|ours - ref32| <= 1e-4" cannot be asserted end to end.  What
+    can: our end-to-end map -- own producers, bf16-split products, graph replay: every difference from the reference's
+    pipeline at once -- is as close to the fp64 result as the reference's fp32 map is,
+          median_i d(ours_i, ref64_i)  <=  k_median * median_i d(ref32_i, ref64_i)
+    for d = min-max-normalised L-inf (what imagenet_seg_eval.py:217 consumes) and d = relative L2, and no single sample is
+    off by more than k_each times its own reference distance (a gross error would be orders of magnitude).  Per-sample
+    ratios are heavy-tailed (each is one draw of the noise against another), hence medians."""
+    import numpy as np
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_fp64.npz"))
+    idx = [int(i) for i in fx[prefix + ".samples"]]
+    ref32 = torch.from_numpy(fx[prefix + ".ref32"]).double()
+    ref64 = torch.from_numpy(fx[prefix + ".ref64"]).double()
+    got = ours.detach().double().cpu()
+    assert got.shape == ref64.shape and torch.isfinite(got).all(), (name, got.shape, ref64.shape)
+
+    def mm(m):
+        lo, hi = m.min(), m.max()
+        return (m - lo) / (hi - lo)
+
+    rows = []
+    for n_, i in enumerate(idx):
+        a, r32, r64 = got[n_].reshape(-1), ref32[n_].reshape(-1), ref64[n_].reshape(-1)
+        d_o = (float((mm(a) - mm(r64)).abs().max()), float((a - r64).norm() / r64.norm()))
+        d_r = (float((mm(r32) - mm(r64)).abs().max()), float((r32 - r64).norm() / r64.norm()))
+        rows.append({"sample": i, "ours_norm_linf": d_o[0], "ref32_norm_linf": d_r[0], "ours_rel_l2": d_o[1],
+                     "ref32_rel_l2": d_r[1]})
+    med = lambda key: float(np.median([r[key] for r in rows]))      # noqa: E731
+    summary = {"samples": len(rows), "median_ours_norm_linf": med("ours_norm_linf"), "median_ref32_norm_linf": med("ref32_norm_linf"),
+               "median_ours_rel_l2": med("ours_rel_l2"), "median_ref32_rel_l2": med("ref32_rel_l2"), "k_median": k_median}
+    summary["ratio_norm_linf"] = summary["median_ours_norm_linf"] / max(summary["median_ref32_norm_linf"], 1e-300)
+    summary["ratio_rel_l2"] = summary["median_ours_rel_l2"] / max(summary["median_ref32_rel_l2"], 1e-300)
+    record(name + ".e2e_vs_fp64", **summary, per_sample=rows)
+    assert summary["ratio_norm_linf"] <= k_median, (name, summary)
+    assert summary["ratio_rel_l2"] <= k_median, (name, summary)
+    for r in rows:      # no gross error on any sample (2e-5: the floor below which the normalised statistic is rounding)
+        assert r["ours_norm_linf"] <= k_each * r["ref32_norm_linf"] + 2e-5, (name, r)
+        assert r["ours_rel_l2"] <= k_each * r["ref32_rel_l2"] + 2e-5, (name, r)
+    return summary
+
+
 # ------------------------------------------------------------------------------------------ tiny ViT (golden)
 @pytest.mark.parametrize("variant", ["ours", "lrp"])
 def test_vit_tiny_golden(golden_vit_tiny, variant):
@@ -833,6 +878,8 @@ def test_config1_vit_b16_batch64(vit_b16, golden_bands):
         lrp_ov = LRP(model, overlap_backward=True)
         g = GraphedCall(lambda t: lrp_ov.generate_LRP(t, method="transformer_attribution", start_layer=1), (x,))
         assert torch.equal(g(x), maps)
+        # ... and that map, end to end against the reference run in fp64 (16 samples of the batch, start_layer = 1)
+        _e2e_vs_fp64("vit_b16_b64.bench_path.sl1", maps[list(range(0, B, 4))], "vit_b16_b64.sl1", k_median=1.5)
         x2 = seeded_randn((B, 3, 224, 224), 9).to(dev())
         rep = g(x2).clone()
         assert torch.equal(rep, lrp.generate_LRP(x2, method="transformer_attribution", start_layer=1))
@@ -905,6 +952,8 @@ def _config2_body(model, lrp, producers):
                 assert torch.equal(one, maps[i:i + 1])
         ref = O.vit_relprop(oh[i:i + 1].cpu(), cache, num_heads=16, start_layer=1)
         _assert_map(f"vit_l16_384.{producers}.oracle.map_sl1.{i}", maps[i:i + 1], ref["map"], norm_tol=1e-4, rel_tol=3e-4)
+    if B == 32:      # end to end against the reference run in fp64 (four samples; a small set: the bar is looser)
+        _e2e_vs_fp64(f"vit_l16_384.{producers}.sl1", maps[[3, 10, 21, 31]], "vit_l16_384_b32.sl1", k_median=3.0)
     # conservation over the whole batch
     cam = model.head.relprop(oh, alpha=1)
     cam = model.pool.relprop(cam.unsqueeze(1), alpha=1)
@@ -952,6 +1001,7 @@ def _config3_body(model, producers):
     sums = cam.double().sum(dim=(1, 2)).cpu()
     record(f"bert_base_512.{producers}.conservation", min=float(sums.min()), max=float(sums.max()))
     assert (sums - 1.0).abs().max() < 2e-3
+    _e2e_vs_fp64(f"bert_base_512.{producers}.sl0", out[[0, 1, 14, 31]], "bert_base_512_b32.sl0", k_median=3.0)
     for i in (0, 1, 14, 31):       # padded, unpadded, padded, unpadded: four of 32, literal 1e-4 bar
         with sliced_relprop_state(model, i, B):
             cache = bert_cache_from_model(model)
