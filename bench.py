@@ -231,30 +231,34 @@ KERNEL_GROUPS = {
     # timer name: (device kernels, reference rule)
     "linear_x6_cpass": ("x6_kernel<WM, MODE_C, 0, 2, 1> (rocprofv3 prints the numbers: <2, 1, 0, 2, 1>)", "Linear.relprop C-pass on bf16 MFMAs (P+ and P- side by side: 12 bf16 "
                                                 "products of 2*T*in*out flops), layers_ours.py:220-225"),
-    "linear_x6_zpass": ("x6_kernel<WM, MODE_Z, 0, 2, KSPLIT> (<2, 0, 0, 2, 1>; fc2: <2, 0, 0, 2, 2>; proj: <0, 0, 0, 2, 1>)", "Linear.relprop Z-pass from the forward output on bf16 MFMAs (6 products), "
+    "linear_x6_zpass": ("x6_kernel<WM, MODE_Z, 0, 2, 1> (<2, 0, 0, 2, 1>; proj: <0, 0, 0, 2, 1>)", "Linear.relprop Z-pass from the forward output on bf16 MFMAs (6 products), "
                                                 "S written as bf16 planes, layers_ours.py:216-219"),
     "linear_x6_split": ("zero_words_kernel + split_kernel<OP_ABS>", "|X| -> three bf16 planes in MFMA-fragment order"),
     "linear_x6_general": ("split_kernel<OP_POS / OP_NEG> + x6_kernel<., MODE_Z1> x 2 + x6_kernel<., MODE_X> x 2 (variant lrp) | "
                           "x6_kernel<., MODE_Z / MODE_C / MODE_ZI / MODE_CI> (ours, alpha != 1)",
                           "Linear.relprop for variant lrp / alpha != 1 on bf16 MFMAs: one-sided products, 24 (lrp) or 18 (ours) "
                           "bf16 product units of 2*T*in*out per half, layers_lrp.py:188-211, layers_ours.py:225-228"),
-    "linear_forward_x6": ("split_kernel<OP_ID> + x6_kernel<WM, MODE_G, 0, 2, KSPLIT>", "producer: y = x W^T + b (nn.Linear, "
+    "linear_forward_x6": ("split_kernel<OP_ID> (fc2: none, GELU emitted the planes) + x6_kernel<WM, MODE_G, 0, 2, 1>", "producer: y = x W^T + b (nn.Linear, "
                           "layers_ours.py:207) on bf16 MFMAs, 6 products of 2*T*in*out flops"),
-    "linear_backward_x6": ("split_kernel<OP_ID> + x6_kernel<WM, MODE_G, 0, 2, KSPLIT>", "producer: d_x = d_y W on bf16 MFMAs"),
+    "linear_backward_x6": ("split_kernel<OP_ID> (fc1: none, GELU's backward emitted the planes) + x6_kernel<WM, MODE_G, 0, 2, 1>",
+                           "producer: d_x = d_y W on bf16 MFMAs"),
     "linear_cpass": ("linear_k2_kernel<0,false,false>", "Linear.relprop C-pass, layers_ours.py:220-225"),
     "linear_zpass_fwd": ("linear_k1_kernel<ZM_FWD>", "Linear.relprop Z-pass from the forward output, layers_ours.py:216-219"),
     "linear_zpass": ("linear_k1_kernel<ZM_OURS>", "Linear.relprop Z-pass (two products), layers_ours.py:216-219"),
-    "attention_av_rule": ("av_rule_kernel", "einsum 'bhij,bhjd->bhid' / MatMul rule, layers_ours.py:48-60"),
+    "attention_av_rule": ("te_attn_kb::av6_kb_kernel<RULE> (round 5: wave-owned key blocks, bf16 MFMAs with split operands)",
+                          "einsum 'bhij,bhjd->bhid' / MatMul rule, layers_ours.py:48-60"),
     "attention_qk_rule": ("qk_rule_kernel", "einsum 'bhid,bhjd->bhij' / MatMul rule, layers_ours.py:48-60"),
     "attention_fused_rules": ("attn_rules_kernel", "both attention rules of a ViT block in one pass, ViT_LRP.py:157-173"),
     "attention_forward": ("attn_fwd_kernel", "producer: scores + softmax + attn v, ViT_LRP.py:132-152"),
-    "attention_backward": ("av_rule_kernel<BWD> + qk_rule_kernel<BWD>", "producer: attention-gradient backward, "
+    "attention_backward": ("te_attn_kb::av6_kb_kernel<BWD> (d_attn, d_v) + qk_rule_kernel<BWD>", "producer: attention-gradient backward, "
                                                                          "ViT_LRP.py:144-145"),
     "layernorm_forward": ("ln_fwd_kernel", "producer: LayerNorm forward, layers_ours.py:76 (ViT_LRP.py:184,187,266)"),
     "layernorm_backward": ("ln_bwd_kernel", "producer: LayerNorm input gradient (+ the bypass gradient of the residual "
                                             "block), ViT_LRP.py:203-205"),
-    "gelu_forward": ("gelu_fwd_kernel", "producer: GELU forward, layers_ours.py:70 (ViT_LRP.py:57)"),
-    "gelu_backward": ("gelu_bwd_kernel", "producer: GELU input gradient"),
+    "gelu_forward": ("gelu_split_lds_kernel<SRC_GELU_FWD> (fp32 output + the operand planes of fc2's forward product and rule; "
+                     "gelu_fwd_kernel where no x6 Linear follows)", "producer: GELU forward, layers_ours.py:70 (ViT_LRP.py:57)"),
+    "gelu_backward": ("gelu_split_lds_kernel<SRC_GELU_BWD> (the gradient leaves as the operand planes of fc1's input-gradient "
+                      "product, no fp32 tensor; gelu_bwd_kernel otherwise)", "producer: GELU input gradient"),
     "add_deferred": ("add_deferred_kernel + add_factors_kernel", "Add.relprop (one pass; rescale applied by the "
                                                                  "consumers), layers_ours.py:97-120"),
     "add": ("add_sums_kernel + add_apply_kernel", "Add.relprop, layers_ours.py:97-120"),
@@ -822,6 +826,7 @@ def main():
                                                2: "256 x 256 tiles where the shape allows (the step runs concurrent streams)",
                                                3: "128 x 128 tiles"}[ops.X6_TILE],
                                    "extra_flags": hex(ops.X6_FLAGS)},
+                       "gelu_emits_operand_planes": bool(ops.X6_FUSE_GELU and ops.USE_FUSED_PRODUCERS and ops.X6_GEMM != "off"),
                        "relprop_beside_backward": args.overlap_backward == "on",
                        "blocks_below_start_layer_pruned": args.prune == "on",
                        "producers": "fused attention forward/backward kernels" if fused_on else "stock",

@@ -363,6 +363,19 @@ int te_gemm_x6_f32(const float* X, const void* x_planes, const void* w_planes, c
  * is |X| |W|^T).  Both buffers te_linear_x6_planes_bytes(rows, K) bytes; planes_bytes = the size of each. */
 int te_linear_x6_split_dual_f32(const float* A, int64_t rows, int64_t K, void* planes, void* planes_abs,
                                 size_t planes_bytes, te_stream_t stream);
+/* nn.GELU between the two Linear layers of an Mlp block (modules/layers_ours.py:70; ViT_LRP.py:57-69: fc1 -> act -> fc2;
+ * BERT.py BertIntermediate) as a producer of operand planes -- the split passes of its two neighbours disappear (round 5):
+ *   te_gelu_backward_x6_planes_f32  planes of d_h = d_a . gelu'(h), [rows, K] row-major inputs: the x_planes of the
+ *                                   te_gemm_x6_f32 that forms fc1's input gradient.  Bit for bit the planes
+ *                                   te_linear_x6_split_matrix_f32 builds from te_gelu_backward_f32's output, which is never
+ *                                   written.
+ *   te_gelu_forward_x6_planes_f32   y = gelu(x) as fp32 (te_gelu_forward_f32's bits) AND the two plane sets
+ *                                   te_linear_x6_split_dual_f32 builds from y (fc2's forward product, fc2's rule).
+ * K % 16 == 0; planes / planes_abs: te_linear_x6_planes_bytes(rows, K) bytes each = planes_bytes. */
+int te_gelu_backward_x6_planes_f32(const float* dy, const float* x, int64_t rows, int64_t K, void* planes,
+                                   size_t planes_bytes, te_stream_t stream);
+int te_gelu_forward_x6_planes_f32(const float* x, float* y, int64_t rows, int64_t K, void* planes, void* planes_abs,
+                                  size_t planes_bytes, te_stream_t stream);
 
 /* ---- producers of the cached tensors ----------------------------------------------------
  * The attention block of baselines/ViT/ViT_LRP.py:132-152 (and its gradient, the tensor save_attn_gradients receives,

@@ -75,5 +75,6 @@ for r in range(2):
             print(f"   first differing op: #{i} {n0} (previous op: {prev}); max abs diff per output {dd}; shapes {[tuple(u.shape) for u in t0]}", flush=True)
             break
 g = GraphedCall(lambda t: lrp_ov.generate_LRP(t, method="transformer_attribution", start_layer=1), (x,))
-for r in range(10):
+NREP = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+for r in range(NREP):
     compare(f"graph replay {r}", g(x))

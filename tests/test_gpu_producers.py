@@ -389,6 +389,87 @@ def test_gelu_producer(shape):
     assert torch.equal(ops.gelu_forward(x[:1].contiguous()), y[:1])
 
 
+@pytest.mark.parametrize("shape", [(2, 197, 3072), (1, 50, 4096), (3, 11, 144), (1, 33, 16)])
+def test_gelu_producers_emit_operand_planes(shape):
+    """Round 5: the GELU producers that write operand planes themselves.  te_gelu_forward_x6_planes_f32 =
+    te_gelu_forward_f32's bits plus the two plane sets te_linear_x6_split_dual_f32 builds from them;
+    te_gelu_backward_x6_planes_f32 = the planes te_linear_x6_split_matrix_f32 builds from te_gelu_backward_f32's output --
+    bit for bit (ragged last row block and a last group of K16 steps that is not full included)."""
+    from transformer_explainability_amd import _lib, ops
+    d = dev()
+    lib = _lib.load()
+    x = (rnd(shape, 91) * 3.0).to(d)
+    x.view(-1)[:4] = torch.tensor([0.0, -0.0, 30.0, -30.0], device=d)
+    dy = rnd(shape, 92).to(d)
+    K = shape[-1]
+    T = x.numel() // K
+    nb = lib.te_linear_x6_planes_bytes(T, K)
+    s = torch.cuda.current_stream().cuda_stream
+    y0, dx0 = ops.gelu_forward(x), ops.gelu_backward(dy, x)
+    ref = [torch.zeros(nb, dtype=torch.uint8, device=d) for _ in range(3)]
+    _lib.check(lib.te_linear_x6_split_dual_f32(y0.data_ptr(), T, K, ref[0].data_ptr(), ref[1].data_ptr(), nb, s), "dual")
+    _lib.check(lib.te_linear_x6_split_matrix_f32(dx0.data_ptr(), T, K, 0, ref[2].data_ptr(), nb, s), "signed")
+    y1, xs, xa = ops.gelu_forward_planes(x)
+    dxp = ops.gelu_backward_planes(dy, x)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0)
+    assert torch.equal(xs[:nb], ref[0]) and torch.equal(xa[:nb], ref[1])
+    assert torch.equal(dxp[:nb], ref[2])
+
+
+def test_mlp_block_gelu_hands_planes_to_its_neighbours():
+    """vit.Mlp (ViT_LRP.py:57-74: fc1 -> GELU -> fc2) with the Linear layers on the x6 kernels: the activation emits fc2's
+    operand planes in its forward pass and fc1's input-gradient operand in its backward pass (producers._Gelu) -- output,
+    input gradient and the relprop result are bitwise those of the separate split passes (ops.X6_FUSE_GELU = False), the
+    fused kernels are the ones that ran, and a second consumer of the hidden gradient would read NaN, never stale memory."""
+    from transformer_explainability_amd import ops, producers, rules, vit
+    d = dev()
+    torch.manual_seed(3)
+    mlp = vit.Mlp(768, 3072).to(d).eval()
+    x = rnd((4, 197, 768), 95).to(d).requires_grad_(True)
+    g = rnd((4, 197, 768), 96).to(d)
+    R = rnd((4, 197, 768), 97, 1e-3).to(d)
+    was = (ops.USE_FUSED_PRODUCERS, ops.X6_GEMM, ops.X6_FUSE_GELU)
+    ops.USE_FUSED_PRODUCERS, ops.X6_GEMM = True, "all"
+    calls = {"fwd": 0, "bwd": 0}
+    f0, b0 = ops.gelu_forward_planes, ops.gelu_backward_planes
+
+    def fwd(*a):
+        calls["fwd"] += 1
+        return f0(*a)
+
+    def bwd(*a):
+        calls["bwd"] += 1
+        return b0(*a)
+
+    ops.gelu_forward_planes, ops.gelu_backward_planes = fwd, bwd
+    try:
+        outs = []
+        for fuse in (False, True):
+            ops.X6_FUSE_GELU = fuse
+            y = mlp(x)
+            (dx,) = torch.autograd.grad(y, x, g)
+            cam = mlp.relprop(R, alpha=1.0)
+            outs.append((y.detach().clone(), dx.clone(), cam.clone()))
+            assert "dy_planes_from_consumer" not in rules.x6_cache(mlp.fc1)      # consumed by fc1's backward
+            assert "x_planes_from_producer" not in rules.x6_cache(mlp.fc2)       # consumed by fc2's forward
+        assert calls == {"fwd": 1, "bwd": 1}
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert torch.isfinite(outs[1][1]).all()
+        # the placeholder autograd carries between the two nodes: NaN for anyone but fc1's input-gradient product
+        ops.X6_FUSE_GELU = True
+        h = mlp.fc1(x)
+        a = mlp.act(h)
+        (dh,) = torch.autograd.grad(a, h, rnd((4, 197, 3072), 98).to(d))
+        assert dh.shape == h.shape and not any(dh.stride()) and torch.isnan(dh).all()
+        rules.x6_cache(mlp.fc1).pop("dy_planes_from_consumer", None)
+        rules.x6_cache(mlp.fc2).pop("x_planes_from_producer", None)
+    finally:
+        ops.gelu_forward_planes, ops.gelu_backward_planes = f0, b0
+        ops.USE_FUSED_PRODUCERS, ops.X6_GEMM, ops.X6_FUSE_GELU = was
+
+
 def test_residual_layernorm_node(fused):
     """producers._ResidualLayerNorm (clone -> norm of a pre-norm block as one autograd node) gives the same values and
     the same input gradient as the two stock nodes."""

@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TE_RELPROP_LIB") or os.path.join(_PKG, "lib", "libte_relprop.so")
 
 TE_OK = 0
-MIN_LIB_VERSION = 500      # te_version(): 0.5.0, the round-5 ABI
+MIN_LIB_VERSION = 501      # te_version(): 0.5.1, the round-5 ABI (+ the plane-emitting GELU producers)
 TE_ERR_UNSUPPORTED = -3
 TE_VARIANT_OURS = 0
 TE_VARIANT_LRP = 1
@@ -85,6 +85,8 @@ SIGNATURES = {
     "te_layernorm_backward_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "te_gelu_forward_f32": (_I, [_P, _P, _I64, _P]),
     "te_gelu_backward_f32": (_I, [_P, _P, _P, _I64, _P]),
+    "te_gelu_backward_x6_planes_f32": (_I, [_P, _P, _I64, _I64, _P, _SZ, _P]),
+    "te_gelu_forward_x6_planes_f32": (_I, [_P, _P, _I64, _I64, _P, _P, _SZ, _P]),
     "te_matmul_relprop_qk_fwd_f32": (_I, [_P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64,
                                           _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_matmul_relprop_qk_fwd_scaled_f32": (_I, [_P, _P, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _I64,

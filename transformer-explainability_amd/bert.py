@@ -276,6 +276,9 @@ def make_bert_module(L):
             self.intermediate = BertIntermediate(config)
             self.output = BertOutput(config)
             self.clone = L.Clone()
+            act = self.intermediate.intermediate_act_fn
+            if hasattr(act, "feeds"):
+                act.feeds(self.output.dense)      # (a hint for the producers: GELU may emit output.dense's operand planes)
 
         def forward(self, hidden_states, attention_mask=None, head_mask=None, **unused):
             att = self.attention(hidden_states, attention_mask, head_mask)[0]

@@ -3,7 +3,7 @@
 
 #include <string.h>
 
-extern "C" int te_version(void) { return 500; /* 0.5.0: round 5 -- study schedules out of the shipped build (te_x6_study_build) */ }
+extern "C" int te_version(void) { return 501; /* 0.5.1: round 5 -- study schedules out of the shipped build (te_x6_study_build); GELU producers that emit operand planes */ }
 
 extern "C" int te_x6_study_build(void) {
 #ifdef TE_X6_STUDY

@@ -18,6 +18,18 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// nn.GELU, exact erf form (modules/layers_ours.py:70, ViT_LRP.py:57) and its derivative times an incoming gradient: ONE
+// definition for the stand-alone producers (te_norm_act.hip) and for the producers that emit operand planes instead of
+// fp32 (te_linear_x6.hip), so that both give the same bits.
+constexpr float kTeInvSqrt2 = 0.70710678118654752440f;
+constexpr float kTeInvSqrt2Pi = 0.39894228040143267794f;      // 1 / sqrt(2 pi)
+__device__ __forceinline__ float te_gelu(float v) { return (v * 0.5f) * (1.0f + erff(v * kTeInvSqrt2)); }
+__device__ __forceinline__ float te_gelu_grad(float g, float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * kTeInvSqrt2));
+  const float pdf = expf(-0.5f * (v * v)) * kTeInvSqrt2Pi;
+  return g * (cdf + v * pdf);
+}
+
 // safe_divide of the reference (modules/layers_ours.py:10-13), evaluated exactly as the reference
 // does in fp32: den = b + 1e-9 (one rounding), an exact-zero den is replaced by 1e-9, IEEE
 // division, then a multiplication by the 0/1 mask (b != 0).  Compiled with -ffp-contract=off.

@@ -50,6 +50,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "te_common.h"
@@ -181,6 +182,159 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ sr
         }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Producers that emit operand planes themselves (round 5): nn.GELU between the two Linear
+// layers of an Mlp block (ViT_LRP.py:57-69, BERT.py: BertIntermediate).  Thread mapping and plane layout of split_kernel.
+//   SRC_GELU_BWD  d_h = d_a . gelu'(h) goes straight into the planes of fc1's input-gradient product (te_gemm_x6_f32's
+//                 x_planes): the fp32 d_h is never written or read (22 -> 14 B per element against the two passes it replaces)
+//   SRC_GELU_FWD  a = gelu(h) is written as fp32 (the rule and the backward pass read it) AND as the signed planes of fc2's
+//                 forward product plus the planes of |a| for fc2's rule (te_linear_x6_split_dual_f32's outputs, bit for bit)
+// ------------------------------------------------------------------------------------------------
+enum { SRC_GELU_BWD = 0, SRC_GELU_FWD = 1 };
+template <int SRC>
+__global__ __launch_bounds__(256) void gelu_split_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                         float* __restrict__ y, unsigned char* __restrict__ dst,
+                                                         unsigned char* __restrict__ dst_abs, int64_t R, int64_t K) {
+  const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t rb = blockIdx.x;
+  const int64_t ks = (int64_t)blockIdx.y * 8 + sl;
+  const int64_t nks = K >> 4;
+  if (ks >= nks) return;
+  const int64_t row = rb * 32 + r;
+  float v[16];
+  if (row < R) {
+    const int64_t at = row * K + ks * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + at + 4 * c);
+      if constexpr (SRC == SRC_GELU_BWD) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + at + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * c + e] = te_gelu_grad(gv[e], xv[e]);
+      } else {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[4 * c + e] = te_gelu(xv[e]);
+        *reinterpret_cast<f32x4*>(y + at + 4 * c) = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.0f;
+  }
+  unsigned p[8][3];                    // [pair of consecutive k][plane]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3_pk(v[2 * e], v[2 * e + 1], p[e]);
+  auto store = [&](unsigned char* d) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = p[4 * kh + e][q];
+        *reinterpret_cast<u32x4*>(d + q * kFrag + kh * 512) = w;
+      }
+  };
+  store(dst + ((rb * nks + ks) * 3) * kFrag + r * 16);
+  if constexpr (SRC == SRC_GELU_FWD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {      // planes of |a| from the planes of a: as split_kernel's dst_abs
+      const unsigned m = p[e][0] & 0x80008000u;
+      p[e][0] &= 0x7fff7fffu;
+      p[e][1] ^= m & (((p[e][1] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u);
+      p[e][2] ^= m & (((p[e][2] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u);
+    }
+    store(dst_abs + ((rb * nks + ks) * 3) * kFrag + r * 16);
+  }
+}
+
+// The same producers with the elementwise work in a COALESCED mapping: a block's 32 rows x 128 k tile is read as 1024
+// float4 (a wave covers 512 contiguous bytes of two rows per instruction, four values per thread and step -- the shape of the
+// stand-alone gelu kernels), the results cross to split_kernel's (row, K16 step) mapping through LDS, and only the split and
+// the plane stores run there.  gelu_split_kernel above does the erf / exp arithmetic on 16 values per thread behind
+// row-strided loads; measured against it in round 5.
+constexpr int kGsPitch = 132;               // floats per tile row in LDS: 128 + 4 (16-B reads of 32 rows hit every bank once)
+template <int SRC>
+__global__ __launch_bounds__(256) void gelu_split_lds_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                             float* __restrict__ y, unsigned char* __restrict__ dst,
+                                                             unsigned char* __restrict__ dst_abs, int64_t R, int64_t K) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * kGsPitch];
+  const int64_t rb = blockIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.y * 128;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    const int tr = i >> 5, c4 = i & 31;
+    const int64_t row = rb * 32 + tr, col = k0 + 4 * c4;
+    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (row < R && col < K) {                        // (K % 16 == 0: a float4 never straddles the end of a row)
+      const int64_t at = row * K + col;
+      const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + at));
+      if constexpr (SRC == SRC_GELU_BWD) {
+        const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + at));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = te_gelu_grad(gv[e], xv[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = te_gelu(xv[e]);
+        *reinterpret_cast<f32x4*>(y + at) = o;
+      }
+    }
+    *reinterpret_cast<f32x4*>(&tile[tr * kGsPitch + 4 * c4]) = o;
+  }
+  __syncthreads();
+  const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t ks = (int64_t)blockIdx.y * 8 + sl;
+  const int64_t nks = K >> 4;
+  if (ks >= nks) return;
+  float v[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(&tile[r * kGsPitch + sl * 16 + 4 * c]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * c + e] = q[e];
+  }
+  unsigned p[8][3];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split3_pk(v[2 * e], v[2 * e + 1], p[e]);
+  auto store = [&](unsigned char* d) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = p[4 * kh + e][q];
+        *reinterpret_cast<u32x4*>(d + q * kFrag + kh * 512) = w;
+      }
+  };
+  store(dst + ((rb * nks + ks) * 3) * kFrag + r * 16);
+  if constexpr (SRC == SRC_GELU_FWD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned m = p[e][0] & 0x80008000u;
+      p[e][0] &= 0x7fff7fffu;
+      p[e][1] ^= m & (((p[e][1] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u);
+      p[e][2] ^= m & (((p[e][2] & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u);
+    }
+    store(dst_abs + ((rb * nks + ks) * 3) * kFrag + r * 16);
+  }
+}
+
+// (measurement builds: TE_GELU_SPLIT=direct runs gelu_split_kernel instead)
+static bool gelu_split_staged() {
+#ifdef TE_STUDY
+  static const bool on = [] {
+    const char* e = getenv("TE_GELU_SPLIT");
+    return !(e && !strcmp(e, "direct"));
+  }();
+  return on;
+#else
+  return true;
+#endif
 }
 
 __global__ __launch_bounds__(256) void zero_words_kernel(u32x4* __restrict__ p) {
@@ -1129,6 +1283,39 @@ extern "C" int te_linear_x6_split_dual_f32(const float* A, int64_t rows, int64_t
   const dim3 grid((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8));
   split_kernel<OP_ID, false><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(A, (unsigned char*)planes, rows, K, 3, 0,
                                                                           (unsigned char*)planes_abs);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// GELU producers that write operand planes (gelu_split_kernel above); planes / planes_abs: te_linear_x6_planes_bytes(rows, K)
+extern "C" int te_gelu_backward_x6_planes_f32(const float* dy, const float* x, int64_t rows, int64_t K, void* planes,
+                                              size_t planes_bytes_, te_stream_t stream_) {
+  if (!dy || !x || !planes || rows < 1) return TE_ERR_INVALID_ARG;
+  if (K < 16 || K % 16 || !te_aligned16(dy) || !te_aligned16(x) || rows > ((int64_t)1 << 26)) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes)) return TE_ERR_WORKSPACE;
+  const dim3 grid((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8));
+  if (gelu_split_staged())
+    gelu_split_lds_kernel<SRC_GELU_BWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(dy, x, nullptr, (unsigned char*)planes,
+                                                                                     nullptr, rows, K);
+  else
+    gelu_split_kernel<SRC_GELU_BWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(dy, x, nullptr, (unsigned char*)planes,
+                                                                                 nullptr, rows, K);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+extern "C" int te_gelu_forward_x6_planes_f32(const float* x, float* y, int64_t rows, int64_t K, void* planes, void* planes_abs,
+                                             size_t planes_bytes_, te_stream_t stream_) {
+  if (!x || !y || !planes || !planes_abs || rows < 1) return TE_ERR_INVALID_ARG;
+  if (K < 16 || K % 16 || !te_aligned16(x) || !te_aligned16(y) || rows > ((int64_t)1 << 26)) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes) || !te_aligned16(planes_abs)) return TE_ERR_WORKSPACE;
+  const dim3 grid((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8));
+  if (gelu_split_staged())
+    gelu_split_lds_kernel<SRC_GELU_FWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(nullptr, x, y, (unsigned char*)planes,
+                                                                                     (unsigned char*)planes_abs, rows, K);
+  else
+    gelu_split_kernel<SRC_GELU_FWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(nullptr, x, y, (unsigned char*)planes,
+                                                                                 (unsigned char*)planes_abs, rows, K);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }

@@ -134,16 +134,13 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(const float* __restric
   }
 }
 
-constexpr float kInvSqrt2 = 0.70710678118654752440f;
-constexpr float kInvSqrt2Pi = 0.39894228040143267794f;      // 1 / sqrt(2 pi)
-
 __global__ __launch_bounds__(kThreads) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n4) return;
   const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + i);
   f32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (v[e] * 0.5f) * (1.0f + erff(v[e] * kInvSqrt2));
+  for (int e = 0; e < 4; ++e) o[e] = te_gelu(v[e]);
   __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(y) + i);
 }
 
@@ -155,11 +152,7 @@ __global__ __launch_bounds__(kThreads) void gelu_bwd_kernel(const float* __restr
   const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + i);
   f32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float cdf = 0.5f * (1.0f + erff(v[e] * kInvSqrt2));
-    const float pdf = expf(-0.5f * (v[e] * v[e])) * kInvSqrt2Pi;
-    o[e] = g[e] * (cdf + v[e] * pdf);
-  }
+  for (int e = 0; e < 4; ++e) o[e] = te_gelu_grad(g[e], v[e]);
   __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dx) + i);
 }
 

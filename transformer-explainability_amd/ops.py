@@ -336,6 +336,10 @@ def x6_matrix_planes(W: Tensor, transposed: bool, cache: Optional[dict] = None) 
     return planes
 
 
+def linear_relprop_x6_supported(T: int, in_f: int, out_f: int) -> bool:
+    return bool(_lib.load().te_linear_relprop_x6_supported(int(T), int(in_f), int(out_f)))
+
+
 def gemm_x6_supported(T: int, K: int, M: int) -> bool:
     return bool(_lib.load().te_gemm_x6_supported(int(T), int(K), int(M)))
 
@@ -348,30 +352,41 @@ def _x_abs_key(X: Tensor, T: int, K: int):
 
 
 def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_name: str = "gemm_x6",
-            keep_abs: Optional[dict] = None) -> Tensor:
+            keep_abs: Optional[dict] = None, x_planes: Optional[Tensor] = None) -> Tensor:
     """out [..., M] = X [..., K] . W^T + bias with W as signed planes of an [M, K] matrix (x6_matrix_planes).
     keep_abs: the layer's cache dict -- the split pass then also writes the planes of |X| (bit for bit those of a split of |X|) (te_linear_x6_split_dual_f32) and
-    leaves them there for the layer's relprop rule (linear_relprop: the rule's own split pass over X disappears)."""
+    leaves them there for the layer's relprop rule (linear_relprop: the rule's own split pass over X disappears); a producer
+    of X that emitted both plane sets itself left them under "x_planes_from_producer" (gelu_forward_planes) and the split
+    pass disappears as well.
+    x_planes: the signed planes of X from its producer (gelu_backward_planes) -- X is then used for its shape only and never
+    read (it may be the zero-stride placeholder the producer returned instead of an fp32 tensor)."""
     K = X.shape[-1]
     lead = X.shape[:-1]
-    Xc = _c(X).reshape(-1, K)
-    T = Xc.shape[0]
+    T = X.numel() // K
+    Xc = None if x_planes is not None else _c(X).reshape(-1, K)
+    like = X if Xc is None else Xc
     out = torch.empty((T, M), dtype=torch.float32, device=X.device)
     bc = None if bias is None else _c(bias.detach())
-    with _on_device(Xc) as lib:
-        ws = _ws(lib.te_gemm_x6_workspace_bytes(T, K, M), Xc)
-        with _timed(timer_name, 12.0 * T * K * M, 10.0 * T * K + 6.0 * K * M + 4.0 * T * M):
-            xs = None
-            if (keep_abs is not None and USE_LINEAR_X6 and X6_KEEP_ABS
+    with _on_device(like) as lib:
+        ws = _ws(lib.te_gemm_x6_workspace_bytes(T, K, M), like)
+        x_bytes = (6.0 if x_planes is not None else 10.0) * T * K      # planes read / fp32 read + planes written
+        xs = x_planes
+        if xs is None and keep_abs is not None:
+            hit = keep_abs.pop("x_planes_from_producer", None)
+            if hit is not None and hit[0] == _x_abs_key(X, T, K):
+                xs, x_bytes = hit[1], 6.0 * T * K
+                keep_abs["x_abs_planes"] = (hit[0], hit[2])
+        with _timed(timer_name, 12.0 * T * K * M, x_bytes + 6.0 * K * M + 4.0 * T * M):
+            if (xs is None and keep_abs is not None and USE_LINEAR_X6 and X6_KEEP_ABS
                     and lib.te_linear_relprop_x6_supported(T, K, M)):
                 nb = lib.te_linear_x6_planes_bytes(T, K)
                 xs, xa = _ws(nb, Xc), _ws(nb, Xc)
                 _lib.check(lib.te_linear_x6_split_dual_f32(_ptr(Xc), T, K, _ptr(xs), _ptr(xa), nb, _stream(Xc)),
                            "te_linear_x6_split_dual_f32")
                 keep_abs["x_abs_planes"] = (_x_abs_key(X, T, K), xa)
-            _lib.check(lib.te_gemm_x6_f32(_ptr(Xc), _ptr(xs), _ptr(w_planes), _ptr(bc), _ptr(out), T, K, M,
-                                          (X6_TILE | X6_FLAGS) & ~0x3c00, _ptr(x6_status(Xc.device)), _ptr(ws),
-                                          ws.numel(), _stream(Xc)), "te_gemm_x6_f32")
+            _lib.check(lib.te_gemm_x6_f32(_ptr(Xc) if Xc is not None else None, _ptr(xs), _ptr(w_planes), _ptr(bc), _ptr(out),
+                                          T, K, M, (X6_TILE | X6_FLAGS) & ~0x3c00, _ptr(x6_status(X.device)), _ptr(ws),
+                                          ws.numel(), _stream(like)), "te_gemm_x6_f32")
     return out.reshape(*lead, M)
 
 
@@ -757,6 +772,42 @@ def gelu_forward(x: Tensor) -> Tensor:
     with _on_device(x) as lib, _timed("gelu_forward", 0.0, 4.0 * 2 * x.numel()):
         _lib.check(lib.te_gelu_forward_f32(_ptr(x), _ptr(y), x.numel(), _stream(x)), "te_gelu_forward_f32")
     return y
+
+
+X6_FUSE_GELU = os.environ.get("TE_X6_FUSE_GELU", "1") not in ("", "0")     # measurement switch: GELU emits operand planes
+
+
+def gelu_planes_supported(x: Tensor) -> bool:
+    return bool(X6_FUSE_GELU and x.dim() >= 2 and x.shape[-1] >= 16 and x.shape[-1] % 16 == 0)
+
+
+def gelu_forward_planes(x: Tensor):
+    """y = gelu(x) (gelu_forward's bits) plus the signed planes of y and the planes of |y| -- what gemm_x6's split pass
+    over y would build (te_gelu_forward_x6_planes_f32).  Returns (y, planes, planes_abs)."""
+    x = _c(x)
+    K = x.shape[-1]
+    T = x.numel() // K
+    y = torch.empty_like(x)
+    with _on_device(x) as lib, _timed("gelu_forward", 0.0, (4.0 * 2 + 12.0) * x.numel()):
+        nb = lib.te_linear_x6_planes_bytes(T, K)
+        xs, xa = _ws(nb, x), _ws(nb, x)
+        _lib.check(lib.te_gelu_forward_x6_planes_f32(_ptr(x), _ptr(y), T, K, _ptr(xs), _ptr(xa), nb, _stream(x)),
+                   "te_gelu_forward_x6_planes_f32")
+    return y, xs, xa
+
+
+def gelu_backward_planes(dy: Tensor, x: Tensor) -> Tensor:
+    """The signed planes of dx = dy . gelu'(x), [T, K] with K = x.shape[-1]: the x_planes of the gemm_x6 that consumes the
+    gradient (te_gelu_backward_x6_planes_f32); the fp32 dx is never written."""
+    dy, x = _c(dy), _c(x)
+    K = x.shape[-1]
+    T = x.numel() // K
+    with _on_device(x) as lib, _timed("gelu_backward", 0.0, (4.0 * 2 + 6.0) * x.numel()):
+        nb = lib.te_linear_x6_planes_bytes(T, K)
+        planes = _ws(nb, x)
+        _lib.check(lib.te_gelu_backward_x6_planes_f32(_ptr(dy), _ptr(x), T, K, _ptr(planes), nb, _stream(x)),
+                   "te_gelu_backward_x6_planes_f32")
+    return planes
 
 
 def gelu_backward(dy: Tensor, x: Tensor) -> Tensor:

@@ -60,15 +60,37 @@ class _ResidualLayerNorm(torch.autograd.Function):
 
 
 class _Gelu(torch.autograd.Function):
+    """nn.GELU.  Round 5: between two Linear layers that run on the x6 kernels it emits their operand
+    planes itself (csrc/te_linear_x6.hip: gelu_split_kernel) --
+      forward   feeds = the cache dict of the Linear that consumes the output (rules.GELU.feeds): the output is written as
+                fp32 and as the two plane sets that layer's forward product and rule would otherwise split from it; they wait
+                in that dict under "x_planes_from_producer", keyed on the output tensor (ops.gemm_x6 checks the key);
+      backward  source = the cache dict of the Linear whose output this node received, if that layer forms its input gradient
+                on gemm_x6 (producers.linear marks its output): the gradient leaves this node as planes in that dict
+                ("dy_planes_from_consumer") and as a zero-stride NaN placeholder in autograd's hands -- _Linear.backward
+                recognises the placeholder by its address and never reads it; anything else that consumed it would read
+                NaN, not stale memory."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, feeds, source):
         ctx.save_for_backward(x)
+        ctx.source = source
+        if feeds is not None:
+            y, xs, xa = ops.gelu_forward_planes(x)
+            K = y.shape[-1]
+            feeds["x_planes_from_producer"] = (ops._x_abs_key(y, y.numel() // K, K), xs, xa)
+            return y
         return ops.gelu_forward(x)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.gelu_backward(dy, x)
+        if ctx.source is not None:
+            planes = ops.gelu_backward_planes(dy, x)
+            base = torch.full((1,), float("nan"), dtype=x.dtype, device=x.device)
+            ctx.source["dy_planes_from_consumer"] = (base, tuple(x.shape), planes)
+            return base.expand(x.shape), None, None
+        return ops.gelu_backward(dy, x), None, None
 
 
 class _Linear(torch.autograd.Function):
@@ -90,7 +112,15 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         w = ctx.weight
         if ctx.bwd_x6:
-            dx = ops.gemm_x6(dy, ops.x6_matrix_planes(w, True, ctx.cache), None, w.shape[1], "linear_backward_x6")
+            # the GELU node that consumed this layer's output may have left the gradient as operand planes (_Gelu.backward);
+            # dy is then its zero-stride placeholder, recognised by address and shape, and is never read
+            hit = ctx.cache.pop("dy_planes_from_consumer", None)
+            planes = None
+            if (hit is not None and dy.data_ptr() == hit[0].data_ptr() and tuple(dy.shape) == hit[1]
+                    and not any(dy.stride())):
+                planes = hit[2]
+            dx = ops.gemm_x6(dy, ops.x6_matrix_planes(w, True, ctx.cache), None, w.shape[1], "linear_backward_x6",
+                             x_planes=planes)
         else:
             dx = torch.matmul(dy, w)
         return dx, None, None, None, None, None
@@ -114,7 +144,10 @@ def _d(t):
 
 
 def linear(x, lin, cache, plan):
-    return _Linear.apply(x, _d(lin.weight), _d(lin.bias), cache, plan[0], plan[1])
+    out = _Linear.apply(x, _d(lin.weight), _d(lin.bias), cache, plan[0], plan[1])
+    if plan[1]:
+        out._te_bwd_x6_cache = cache      # (for a GELU that follows: this layer's input gradient takes operand planes)
+    return out
 
 
 def layer_norm(x, norm):
@@ -125,5 +158,14 @@ def residual_layer_norm(x, norm):
     return _ResidualLayerNorm.apply(x, _d(norm.weight), _d(norm.bias), norm.eps)
 
 
-def gelu(x):
-    return _Gelu.apply(x)
+def gelu(x, consumer=None, consumer_cache=None):
+    """consumer: the Linear layer the output goes to, if the caller knows it (rules.GELU.feeds), and its cache dict."""
+    feeds = source = None
+    if ops.gelu_planes_supported(x):
+        if consumer is not None and consumer.weight.shape[1] == x.shape[-1] and linear_plan(x, consumer)[0]:
+            out_f, in_f = consumer.weight.shape
+            if (ops.USE_LINEAR_X6 and ops.X6_KEEP_ABS
+                    and ops.linear_relprop_x6_supported(x.numel() // in_f, in_f, out_f)):
+                feeds = consumer_cache
+        source = getattr(x, "_te_bwd_x6_cache", None)
+    return _Gelu.apply(x, feeds, source)

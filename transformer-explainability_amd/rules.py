@@ -96,10 +96,18 @@ class ReLU(nn.ReLU, RelProp):
 
 
 class GELU(nn.GELU, RelProp):
+    def feeds(self, linear):
+        """Model code may name the Linear layer this activation's output goes to (vit.Mlp, bert.BertLayer): the producer
+        then emits that layer's operand planes itself (producers._Gelu).  A hint only -- the consumer checks that the planes
+        belong to the tensor it received.  Kept in a tuple: not a registered submodule, and copy / pickle follow it."""
+        self.__dict__["_te_feeds"] = (linear,)
+        return self
+
     def forward(self, x):
         from . import producers                      # 8f.1: csrc/te_norm_act.hip behind ops.USE_FUSED_PRODUCERS
         if getattr(self, "approximate", "none") == "none" and not self.training and producers.gelu_usable(x):
-            return producers.gelu(x)
+            nxt = self.__dict__.get("_te_feeds", (None,))[0]
+            return producers.gelu(x, nxt, x6_cache(nxt) if isinstance(nxt, Linear) else None)
         return super().forward(x)
 
 
@@ -156,6 +164,7 @@ class Linear(nn.Linear, RelProp):
         plan = producers.linear_plan(x, self)
         if not plan[0]:
             x6_cache(self).pop("x_abs_planes", None)      # no x6 forward product of THIS input: nothing for the rule to reuse
+            x6_cache(self).pop("x_planes_from_producer", None)
         if plan[0] or plan[1]:
             return producers.linear(x, self, x6_cache(self), plan)
         return super().forward(x)

@@ -105,6 +105,8 @@ def make_vit_module(L):
             self.act = L.GELU()
             self.fc2 = L.Linear(hidden_features, out_features)
             self.drop = L.Dropout(drop)
+            if hasattr(self.act, "feeds"):
+                self.act.feeds(self.fc2)      # (a hint for the producers: the activation may emit fc2's operand planes)
 
         def forward(self, x):
             return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
