@@ -9,7 +9,8 @@ P2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BAN
 P3="FETCH_SIZE"
 P4="WRITE_SIZE"
 i=0
-for P in "$P1" "$P2" "$P3" "$P4"; do
+PASSES=("$P1" "$P2" "$P3" "$P4"); [ -n "$ATTN_PMC_SKIP_P2" ] && PASSES=("$P1" "$P3" "$P4")
+for P in "${PASSES[@]}"; do
   i=$((i+1)); rm -rf gpurun_out/pmc$i
   ( cd /tmp && timeout 250 rocprofv3 --kernel-trace --pmc $P -f csv -d "$ROOT/gpurun_out/pmc$i" -o attn -- \
       python "$ROOT/scripts/attn_bench.py" 64 12 197 64 producers > "$ROOT/gpurun_out/pmc$i.log" 2>&1 )
@@ -19,9 +20,10 @@ import csv, glob, collections, re
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(av_kb_kernel<\d>|qk_kb_kernel<\d>|fwd_rows_kernel|av_rule_kernel<\d>|qk_rule_kernel<\d>|attn_fwd_kernel|qk_finish_kernel)", r["Kernel_Name"])
+        m = re.search(r"(av6?_kb_kernel<\d|qk6?_kb_kernel<\d|fwd_rows_kernel|av_rule_kernel<\d|qk_rule_kernel<\d|attn_fwd_kernel|qk_finish_kernel)", r["Kernel_Name"])
         if m:
-            rows[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            k = m.group(1).replace("av6_", "av_").replace("qk6_", "qk_")
+            rows[k + (">" if "<" in k else "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 B, H, N = 64, 12, 197      # scripts/attn_bench.py's shape; <0> = relprop rule, <1> = the backward producer on the same kernel
 nn, nc = 2 * H * N * N, N * H * 64
 alg = {"av_kb_kernel<0>": (nn + 5 * nc) * 4 * B, "av_kb_kernel<1>": (nn + 4 * nc) * 4 * B, "qk_kb_kernel<0>": (nn + 4 * nc) * 4 * B, "qk_kb_kernel<1>": (nn + 4 * nc) * 4 * B, "fwd_rows_kernel": (nn + 4 * nc) * 4 * B, "av_rule_kernel<0>": (nn + 5 * nc) * 4 * B, "qk_rule_kernel<0>": (nn + 4 * nc) * 4 * B,

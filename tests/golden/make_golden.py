@@ -647,6 +647,67 @@ def make_e2e64():
     print("e2e_fp64.npz", len(out), "arrays")
 
 
+E2E_NOISE_DRAWS = {"vit_b16_b64.sl1": 4, "vit_l16_384_b32.sl1": 8, "bert_base_512_b32.sl0": 6}
+
+
+def make_e2e64_noise():
+    """Adds to e2e_fp64.npz, per sample, the distances to ref64 of the reference's fp32 map under _RoundingNoise draws (one
+    extra fp32 rounding at the output of every Linear / Conv2d: less than another GEMM summation order changes) --
+    `<prefix>.noise_norm_linf` and `.noise_rel_l2`, [samples, draws].  ref32's own distance is ONE draw of a heavy-tailed
+    quantity; these are more draws of the same quantity, from the reference itself."""
+    threads = max(1, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    path = os.path.join(HERE, "e2e_fp64.npz")
+    out = dict(np.load(path))
+
+    def dists(m, r64):
+        a, b = m.double().reshape(-1), torch.from_numpy(r64).double().reshape(-1)
+        mm = lambda t: (t - t.min()) / (t.max() - t.min())      # noqa: E731
+        return float((mm(a) - mm(b)).abs().max()), float((a - b).norm() / b.norm())
+
+    def collect(prefix, run_noisy):
+        idxs = [int(i) for i in out[prefix + ".samples"]]
+        nd = E2E_NOISE_DRAWS[prefix]
+        d0, d1 = np.zeros((len(idxs), nd)), np.zeros((len(idxs), nd))
+        for n_, i in enumerate(idxs):
+            for dr in range(nd):
+                d0[n_, dr], d1[n_, dr] = dists(run_noisy(i, dr), out[prefix + ".ref64"][n_])
+            print(prefix, "sample", i, "ref32-with-noise vs ref64, normalised:", " ".join(f"{v:.2e}" for v in d0[n_]), flush=True)
+        out[prefix + ".noise_norm_linf"], out[prefix + ".noise_rel_l2"] = d0, d1
+
+    vit = rh.load_reference_vit()
+    for prefix, ctor, shape, seed in (("vit_b16_b64.sl1", lambda: vit["ViT_LRP"].vit_base_patch16_224(pretrained=False), (64, 3, 224, 224), 1),
+                                      ("vit_l16_384_b32.sl1", lambda: vit["ViT_LRP"].vit_large_patch16_224(pretrained=False, img_size=384),
+                                       (32, 3, 384, 384), 5)):
+        model = ctor().eval()
+        rh.synthetic_init(model, 0)
+        g32 = vit["gen"].LRP(model)
+        x = rh.seeded_randn(shape, seed)
+
+        def run(i, dr, model=model, g32=g32, x=x):
+            with _RoundingNoise(model, dr):
+                return g32.generate_LRP(x[i:i + 1], method="transformer_attribution", start_layer=1).detach().clone()
+        collect(prefix, run)
+        del model, g32
+    bert = rh.load_reference_bert()
+    from transformers import BertConfig
+    cfg = BertConfig(num_labels=2)
+    cfg.return_dict = False
+    bm = bert["cls"].BertForSequenceClassification(cfg).eval()
+    rh.synthetic_init(bm, 0)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1000, 20000, (32, 512), generator=g)
+    mask = torch.ones(32, 512)
+    mask[::2, 512 - 64:] = 0
+    gb = bert["gen"].Generator(bm)
+
+    def run_b(i, dr):
+        with _RoundingNoise(bm, dr):
+            return gb.generate_LRP(input_ids=ids[i:i + 1], attention_mask=mask[i:i + 1], start_layer=0).detach().clone()
+    collect("bert_base_512_b32.sl0", run_b)
+    np.savez_compressed(path, **out)
+    print("e2e_fp64.npz", len(out), "arrays")
+
 
 if __name__ == "__main__":
     if not rh.reference_available():
@@ -671,5 +732,7 @@ if __name__ == "__main__":
         make_segmentation()
     if "bands" in which:
         make_bands()
+    if "e2e64_noise" in which:
+        make_e2e64_noise()
     if "e2e64" in which:
         make_e2e64()
