@@ -405,3 +405,26 @@ def test_x6_plane_cache_is_scratch_not_state():
     lin3 = pickle.loads(pickle.dumps(lin))
     assert "_te_cache" not in lin3.__dict__
     assert "x6_planes" in rules.x6_cache(lin)                               # the original keeps its planes
+
+
+def test_gelu_consumer_hint_is_not_state():
+    """Round 5: vit.Mlp / bert.BertLayer tell their GELU which Linear layer its output feeds (rules.GELU.feeds), so that on
+    the GPU the activation can emit that layer's operand planes itself (producers._Gelu).  The hint is not a registered
+    submodule (state_dict and parameter lists are untouched), deepcopy follows it to the COPY's layer, a bare GELU has none,
+    and on the CPU path (no HIP producers) the module is plain nn.GELU."""
+    import copy
+    from transformer_explainability_amd import bert, rules, vit
+    mlp = vit.Mlp(16, 64)
+    assert mlp.act.__dict__["_te_feeds"][0] is mlp.fc2
+    assert list(mlp.state_dict().keys()) == ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+    assert [n for n, _ in mlp.act.named_modules()] == [""] and not list(mlp.act.parameters())
+    twin = copy.deepcopy(mlp)
+    assert twin.act.__dict__["_te_feeds"][0] is twin.fc2 and twin.fc2 is not mlp.fc2
+    x = torch.randn(2, 5, 16)
+    assert torch.equal(mlp.eval()(x), mlp.fc2(torch.nn.functional.gelu(mlp.fc1(x))))
+    assert "_te_feeds" not in rules.GELU().__dict__
+    model = bert.BertForSequenceClassification(bert.BertConfigLite(hidden_size=32, num_attention_heads=2, intermediate_size=64,
+                                                                   num_hidden_layers=1, vocab_size=50, num_labels=2))
+    layer = model.bert.encoder.layer[0]
+    assert layer.intermediate.intermediate_act_fn.__dict__["_te_feeds"][0] is layer.output.dense
+    assert not any("act_fn" in k for k in model.state_dict())
