@@ -1085,11 +1085,8 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
     }
   }
 #endif
-  bool fp32 = false;
-#ifdef TE_STUDY
-  if (const char* e = getenv("TE_ATTN_AV")) fp32 = !strcmp(e, "fp32kb");
-#endif
-  if (fp32) {
+#ifdef TE_STUDY      // the fp32-MFMA version of this structure (TE_ATTN_AV=fp32kb): measurement builds only
+  if (const char* e = getenv("TE_ATTN_AV"); e && !strcmp(e, "fp32kb")) {
     if (mode == 0)
       av_kb_kernel<RULE><<<grid, blk, 0, stream>>>(R, rs, Z, zs, attn, v, vs, cam_attn, cam_v, cs, (int)H, (int)N, BH, kbg, scale);
     else
@@ -1097,7 +1094,6 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
                                                   (int)N, BH, kbg, 1.0f);
     return TE_OK;
   }
-#ifdef TE_STUDY
   if (mode == 0) {
     const char* e = getenv("TE_ATTN_KB_PROF");
     if (e && atoi(e) == 1) {

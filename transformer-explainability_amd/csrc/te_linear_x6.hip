@@ -324,18 +324,16 @@ __global__ __launch_bounds__(256) void gelu_split_lds_kernel(const float* __rest
   }
 }
 
-// (measurement builds: TE_GELU_SPLIT=direct runs gelu_split_kernel instead)
-static bool gelu_split_staged() {
+// (measurement builds: TE_GELU_SPLIT=direct runs gelu_split_kernel instead; the shipped build does not instantiate it)
 #ifdef TE_STUDY
+static bool gelu_split_direct() {
   static const bool on = [] {
     const char* e = getenv("TE_GELU_SPLIT");
-    return !(e && !strcmp(e, "direct"));
+    return e && !strcmp(e, "direct");
   }();
   return on;
-#else
-  return true;
-#endif
 }
+#endif
 
 __global__ __launch_bounds__(256) void zero_words_kernel(u32x4* __restrict__ p) {
   p[(size_t)blockIdx.x * 256 + threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
@@ -1294,12 +1292,16 @@ extern "C" int te_gelu_backward_x6_planes_f32(const float* dy, const float* x, i
   if (K < 16 || K % 16 || !te_aligned16(dy) || !te_aligned16(x) || rows > ((int64_t)1 << 26)) return TE_ERR_UNSUPPORTED;
   if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes)) return TE_ERR_WORKSPACE;
   const dim3 grid((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8));
-  if (gelu_split_staged())
-    gelu_split_lds_kernel<SRC_GELU_BWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(dy, x, nullptr, (unsigned char*)planes,
-                                                                                     nullptr, rows, K);
-  else
+#ifdef TE_STUDY
+  if (gelu_split_direct()) {
     gelu_split_kernel<SRC_GELU_BWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(dy, x, nullptr, (unsigned char*)planes,
                                                                                  nullptr, rows, K);
+    TE_RETURN_IF_LAUNCH_FAILED();
+    return TE_OK;
+  }
+#endif
+  gelu_split_lds_kernel<SRC_GELU_BWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(dy, x, nullptr, (unsigned char*)planes,
+                                                                                   nullptr, rows, K);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
@@ -1310,12 +1312,16 @@ extern "C" int te_gelu_forward_x6_planes_f32(const float* x, float* y, int64_t r
   if (K < 16 || K % 16 || !te_aligned16(x) || !te_aligned16(y) || rows > ((int64_t)1 << 26)) return TE_ERR_UNSUPPORTED;
   if (planes_bytes_ < planes_bytes(rows, K) || !te_aligned16(planes) || !te_aligned16(planes_abs)) return TE_ERR_WORKSPACE;
   const dim3 grid((unsigned)te_ceil_div(rows, 32), (unsigned)te_ceil_div(K / 16, 8));
-  if (gelu_split_staged())
-    gelu_split_lds_kernel<SRC_GELU_FWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(nullptr, x, y, (unsigned char*)planes,
-                                                                                     (unsigned char*)planes_abs, rows, K);
-  else
+#ifdef TE_STUDY
+  if (gelu_split_direct()) {
     gelu_split_kernel<SRC_GELU_FWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(nullptr, x, y, (unsigned char*)planes,
                                                                                  (unsigned char*)planes_abs, rows, K);
+    TE_RETURN_IF_LAUNCH_FAILED();
+    return TE_OK;
+  }
+#endif
+  gelu_split_lds_kernel<SRC_GELU_FWD><<<grid, dim3(256), 0, (hipStream_t)stream_>>>(nullptr, x, y, (unsigned char*)planes,
+                                                                                   (unsigned char*)planes_abs, rows, K);
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }
