@@ -53,9 +53,10 @@ int te_version(void);
 const char* te_status_string(int status);
 /* 0 if device 0..n-1 contains a gfx950 agent usable by this library, TE_ERR_NO_DEVICE otherwise */
 int te_device_check(void);
-/* 1 if the library was built with -DTE_X6_STUDY (measurement builds: TE_X6_STAGES_3 / TE_X6_KSPLIT schedules and the
- * main-loop ablations are compiled in), 0 for the shipped library, whose x6 entry points answer TE_ERR_UNSUPPORTED to
- * those flags. */
+/* 0 for the shipped library.  Bit 0: built with -DTE_X6_STUDY (measurement builds: TE_X6_STAGES_3 / TE_X6_KSPLIT schedules
+ * and the main-loop ablations are compiled in; the shipped library's x6 entry points answer TE_ERR_UNSUPPORTED to those
+ * flags).  Bit 1: built with -DTE_STUDY (getenv switches and study variants of the attention, fp32-MFMA and GELU-plane
+ * kernels compiled in). */
 int te_x6_study_build(void);
 
 /* ---- a3  Linear.relprop -------------------------------------------------------------------
@@ -281,7 +282,7 @@ int te_rollout_f32(const float* cams, int64_t L, int64_t start_layer, int64_t B,
  * bit), TE_X6_TILE_128 / TE_X6_TILE_256 pin it; shifted left by TE_X6_TILE_Z_SHIFT / TE_X6_TILE_C_SHIFT they pin one pass.
  * TE_X6_TILE_128x128: 128 x 128 tiles, three 256-thread workgroups per CU (launches with few weight rows).
  * TE_X6_STAGES_3: three LDS stages instead of two in the 256-row geometry (measurement; same results).  STUDY BUILDS ONLY
- * (-DTE_X6_STUDY, te_x6_study_build() == 1): the shipped library does not contain the instantiation and answers
+ * (-DTE_X6_STUDY, te_x6_study_build() & 1): the shipped library does not contain the instantiation and answers
  * TE_ERR_UNSUPPORTED -- likewise TE_X6_KSPLIT.
  *
  * Failure is loud.  A workgroup that continues a tile another workgroup started waits for that one's accumulators for at

@@ -36,7 +36,10 @@ def test_binding_covers_header():
 
 
 def test_version_and_status(lib):
-    assert lib.te_version() >= 500
+    assert lib.te_version() >= 501
+    # the library in the tree is the one that travels to the GPU box: it must be the shipped build, not a measurement build
+    # (TE_BUILD_DEFINES=TE_STUDY / TE_X6_STUDY: getenv switches, study schedules)
+    assert lib.te_x6_study_build() == 0, "a measurement build is in the tree: python transformer-explainability_amd/build.py --force"
     assert lib.te_status_string(0) == b"ok"
     assert b"workspace" in lib.te_status_string(-2)
 

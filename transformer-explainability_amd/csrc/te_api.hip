@@ -6,11 +6,14 @@
 extern "C" int te_version(void) { return 501; /* 0.5.1: round 5 -- study schedules out of the shipped build (te_x6_study_build); GELU producers that emit operand planes */ }
 
 extern "C" int te_x6_study_build(void) {
+  int bits = 0;
 #ifdef TE_X6_STUDY
-  return 1;
-#else
-  return 0;
+  bits |= 1;      // x6 study schedules (TE_X6_STAGES_3 / TE_X6_KSPLIT) and main-loop ablations compiled in
 #endif
+#ifdef TE_STUDY
+  bits |= 2;      // getenv switches and study variants of the attention / fp32-MFMA / GELU-plane kernels compiled in
+#endif
+  return bits;
 }
 
 extern "C" const char* te_status_string(int status) {

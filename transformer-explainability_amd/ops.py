@@ -129,7 +129,7 @@ TE_X6_KSPLIT = 0x8000      # study (off): two K segments per output for long-K /
 def x6_study_build() -> bool:
     """True if the library is a measurement build (-DTE_X6_STUDY: TE_X6_STAGES_3 / TE_X6_KSPLIT compiled in); the shipped
     library answers TE_ERR_UNSUPPORTED (TeError) to those flags."""
-    return bool(_lib.load().te_x6_study_build())
+    return bool(_lib.load().te_x6_study_build() & 1)
 
 
 # A workgroup of an x6 kernel that continues a tile another workgroup started waits for that one's accumulators; the wait
