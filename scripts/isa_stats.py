@@ -40,7 +40,8 @@ def classify(op):
 
 
 def parse_kernels(asm):
-    """-> {mangled name: [lines]} for every function body that ends in s_endpgm."""
+    """-> {mangled name: [lines]} for every function body that contains an s_endpgm (a kernel may have several: an early
+    return of idle waves precedes the main loop of the kb attention kernels), up to its .Lfunc_end label."""
     out, name, body = {}, None, []
     for line in asm.splitlines():
         m = re.match(r"^(_Z\w+|[A-Za-z_]\w*):\s*(;.*)?$", line)
@@ -48,10 +49,12 @@ def parse_kernels(asm):
             name, body = m.group(1), []
             continue
         if name is not None:
-            body.append(line)
-            if "s_endpgm" in line:
-                out[name] = body
+            if line.startswith(".Lfunc_end"):
+                if any("s_endpgm" in b for b in body):
+                    out[name] = body
                 name = None
+                continue
+            body.append(line)
     return out
 
 
