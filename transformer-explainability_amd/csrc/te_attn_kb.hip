@@ -7,19 +7,24 @@
 // Here the N x N operand NEVER touches LDS:
 //
 //   * wave w owns key block jb (32 keys) of its (b, h [, key group]) for the whole kernel.  A [32 rows x 32 keys] block of the
-//     N x N operand is loaded straight into the MFMA ACCUMULATOR layout -- lane (lr, kh) holds column lr, rows
-//     crow(e, kh) = (e & 3) + 8 (e >> 2) + 4 kh, e < 16: sixteen dword loads whose half-waves read 128 contiguous bytes of
-//     one row.  Because the contraction index of an MFMA may be visited in any order, that very register set IS
-//       - the A operand of the column-side product (K = query rows: step e multiplies rows crow(e, 0) | crow(e, 1)),
+//     N x N operand arrives as four 16-byte-per-lane buffer loads (eight rows x 128 contiguous bytes each), requested two
+//     tiles ahead, and changes to the MFMA ACCUMULATOR layout -- lane (lr, kh) holds column lr, rows
+//     crow(e, kh) = (e & 3) + 8 (e >> 2) + 4 kh, e < 16 -- through a wave-private 4.6 KB LDS block (no barrier: a wave's LDS
+//     instructions execute in order).  Because the contraction index of an MFMA may be visited in any order, that very
+//     register set IS
+//       - the A operand of the column-side product (K = query rows in accumulator order),
 //       - the element-wise factor of the row-side result (cam_attn = attn . G lands in the same layout), and
-//       - the layout the N x N result is stored from (sixteen dword stores, 128-byte segments).
-//   * the key-side operand of the row product (v or k of the wave's 32 keys) lives in 32 registers per lane for the whole
-//     kernel; only the [32, 64] row-side tile (S = sd(R, Z), d_out, q) goes through LDS, double-buffered, ONE barrier per tile.
-//   * every load of tile it + 1 is requested before the MFMAs of tile it; stores drain behind them (vmcnt is never waited to
-//     zero inside the loop).
-//
-// Per wave and tile: 64 MFMAs (32 row-side, 32 column-side) against 32 global memory instructions, 8 ds_read_b128, 32
-// ds_read_b32 and ~40 vector-ALU instructions: < 2 other instructions per 64-cycle fp32 MFMA.
+//       - (back through the staging block) the layout the N x N result is stored from, as 16-byte pieces.
+//   * the key-side operand of the row product (v of the wave's 32 keys) lives in registers for the whole kernel; only the
+//     [32, 64] row-side tile (S = sd(R, Z), or d_out) is shared: THREE LDS buffers and an LDS arrival counter instead of a
+//     barrier per tile -- no wave ever waits for another wave's MFMAs.
+//   * the products run on bf16 MFMAs with every fp32 operand split into three bf16 planes, six partial products, fp32
+//     accumulation (av6_kb_kernel, the shipped kernel: fp32 MFMA runs at the fp32 vector rate and its time ADDS to the
+//     vector work of the SIMD -- av_kb_kernel, the fp32-MFMA version of the same structure, is kept for measurement builds).
+//   * global loads and stores of the tile loop are inline asm hipcc's s_waitcnt insertion does not see, waited for with
+//     hand-counted vmcnt; a register with such a load in flight must never be copied -- register sets alternate over a
+//     two-tile loop body, and scripts/check_hidden_loads.py (tests/test_isa_hazards.py) checks the compiled ISA for it.
+//   DESIGN.md, "Attention rules with wave-owned key blocks", has the measurements behind each of these choices.
 //
 // Reductions run in an order that depends on N only: a batch equals its samples run one by one, bit for bit.
 #include <stdlib.h>

@@ -922,10 +922,11 @@ static bool use_kb_av() {
 }
 
 // The QK rule on wave-owned key blocks (te_attn_kb.hip: qk6_kb_kernel) is a STUDY: TE_ATTN_QK=x6 in measurement builds.
-// Round 5 state: correct in every parity test and 4-7 % faster than qk_rule_kernel below (170 vs 177-190 us at N = 197), but
-// inside the replayed ViT-B step (relprop beside the backward pass) 2 of 10 replays differed from the serial step in the
-// last bits of one sample -- a race in its cross-wave exchange of row-product partials that isolated runs (40 x 768
-// workgroups, with and without concurrent attention kernels) never showed.  Not shipped until found.
+// Round 5: correct in every parity test, but 2 of 10 replays of the ViT-B step differed from the serial step in the last bits
+// of one sample -- hipcc had moved a register with a hidden load in flight above its wait and onto the loop back-edge.
+// Fixed (30 of 30 replays bitwise since; scripts/check_hidden_loads.py guards the class), and with that 5-8 % faster than
+// qk_rule_kernel below (172-178 vs 182-192 us at N = 197): its row product is a partial sum per wave that meets in LDS, 900
+// instructions per tile and wave against the AV kernel's 570 -- not enough to replace the kernel every test has run on.
 static bool use_kb_qk() {
 #ifdef TE_STUDY
   static const bool on = [] {
