@@ -58,6 +58,10 @@ int te_device_check(void);
  * flags).  Bit 1: built with -DTE_STUDY (getenv switches and study variants of the attention, fp32-MFMA and GELU-plane
  * kernels compiled in). */
 int te_x6_study_build(void);
+/* Provenance of this binary: "<16 hex>-<8 hex>" = sha256 over csrc/{*.hip,*.h} + include/{*.h} (names and contents,
+ * sorted) and over the compiler flags, baked in by build.py.  The Python loader recomputes the first half from the tree it
+ * was imported from and refuses a library built from other sources; bench.py and smoke() print it. */
+const char* te_build_id(void);
 
 /* ---- a3  Linear.relprop -------------------------------------------------------------------
  * replaces modules/layers_ours.py:207-230 (ours) and modules/layers_lrp.py:188-211 (lrp), and the

@@ -16,6 +16,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Never test a stale library: build.py compares a content hash of csrc/ + include/ with the stamp of the last build
+    (milliseconds when nothing changed) and recompiles what differs; _lib.load() refuses a library of other sources anyway."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_te_build", os.path.join(ROOT, "transformer-explainability_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        mod.build()
+    except RuntimeError as exc:
+        if "hipcc not found" not in str(exc):
+            raise
+
+
 def pytest_collection_modifyitems(config, items):
     """A plain `pytest tests` on a host without an MI355X skips the gpu-marked tests instead of failing 250 times with
     'No HIP GPUs are available'.  The no-silent-fallback guarantee keeps its own CPU test

@@ -118,33 +118,4 @@ def move_relprop_state(model, device):
     return model
 
 
-class sliced_relprop_state:
-    """Context manager: temporarily replace every cached tensor with leading dimension `B` (module attributes
-    X / Y / attn / gradients / masks) by its slice [i:i+1], so that relprop runs on sample i alone -- on exactly
-    the tensors the batched run consumed."""
-
-    def __init__(self, model, i, B):
-        self.model, self.i, self.B = model, i, B
-        self.saved = []
-
-    def _slice(self, v):
-        if torch.is_tensor(v) and v.dim() >= 2 and v.shape[0] == self.B:
-            return v[self.i:self.i + 1]
-        if isinstance(v, (list, tuple)) and v and all(torch.is_tensor(t) for t in v):
-            return type(v)(self._slice(t) for t in v)
-        return v
-
-    def __enter__(self):
-        for m in self.model.modules():
-            for name, val in list(vars(m).items()):
-                if name.startswith("_"):
-                    continue
-                new = self._slice(val)
-                if new is not val:
-                    self.saved.append((m, name, val))
-                    setattr(m, name, new)
-        return self
-
-    def __exit__(self, *a):
-        for m, name, val in self.saved:
-            setattr(m, name, val)
+from oracle.model_cache import sliced_relprop_state  # noqa: E402,F401  (shared with bench.py's parity block)

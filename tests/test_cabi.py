@@ -71,3 +71,22 @@ def test_product_path_fails_loudly_without_gpu():
     x = torch.zeros(2, 8)
     with pytest.raises(TeError):
         ops.clone_relprop([x, x], x)
+
+
+def test_build_id_matches_tree_and_loader_refuses_other_sources(monkeypatch):
+    """te_build_id() = content hash of csrc/ + include/ (+ flags) baked in by build.py; the loader
+    recomputes the source half from the tree and refuses a library built from anything else."""
+    import pytest
+    from transformer_explainability_amd import _buildid, _lib
+    bid = _lib.build_id()
+    src, flags = bid.split("-")
+    assert len(src) == 16 and len(flags) == 8 and src == _buildid.source_hash()
+    assert all(p.endswith((".hip", ".h")) for p in _buildid.source_files()) and len(_buildid.source_files()) >= 16
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_buildid, "source_hash", lambda: "0" * 16)
+    monkeypatch.delenv("TE_RELPROP_LIB", raising=False)
+    monkeypatch.delenv("TE_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(_lib.TeError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load().te_build_id().decode() == bid

@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TE_RELPROP_LIB") or os.path.join(_PKG, "lib", "libte_relprop.so")
 
 TE_OK = 0
-MIN_LIB_VERSION = 501      # te_version(): 0.5.1, the round-5 ABI (+ the plane-emitting GELU producers)
+MIN_LIB_VERSION = 600      # te_version(): 0.6.0, the round-6 ABI (te_build_id)
 TE_ERR_UNSUPPORTED = -3
 TE_VARIANT_OURS = 0
 TE_VARIANT_LRP = 1
@@ -34,6 +34,7 @@ SIGNATURES = {
     "te_status_string": (c_char_p, [_I]),
     "te_device_check": (_I, []),
     "te_x6_study_build": (_I, []),
+    "te_build_id": (c_char_p, []),
     "te_linear_relprop_workspace_bytes": (_SZ, [_I64, _I64, _I64, _I]),
     "te_linear_relprop_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_linear_zpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
@@ -154,8 +155,21 @@ def load():
     if lib.te_version() < MIN_LIB_VERSION:      # a stale in-tree build: argument lists changed (x6 flags / status words)
         raise TeError(f"{LIB_PATH} is version {lib.te_version()}, this package needs >= {MIN_LIB_VERSION}: rebuild it "
                       f"(python transformer-explainability_amd/build.py --force)")
+    # provenance: the library must have been built from the sources of THIS tree (the prebuilt in-tree .so is what reaches the
+    # GPU box; mtimes prove nothing there).  TE_RELPROP_LIB / TE_ALLOW_STALE_LIB=1: measurement builds of other sources.
+    from ._buildid import source_hash
+    bid = (lib.te_build_id() or b"").decode()
+    want = source_hash()
+    if bid.split("-")[0] != want and not (os.environ.get("TE_RELPROP_LIB") or os.environ.get("TE_ALLOW_STALE_LIB") == "1"):
+        raise TeError(f"{LIB_PATH} was built from other sources (te_build_id() = {bid!r}, this tree hashes to {want!r}): "
+                      f"rebuild it (python transformer-explainability_amd/build.py)")
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """te_build_id() of the loaded library: '<source hash>-<flags hash>' (see _buildid.py)."""
+    return (load().te_build_id() or b"").decode()
 
 
 def check(status: int, what: str):

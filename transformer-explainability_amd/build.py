@@ -11,6 +11,7 @@ an rpath fallback for hosts without torch.
 from __future__ import annotations
 
 import argparse
+import importlib.util
 import os
 import shutil
 import subprocess
@@ -54,6 +55,13 @@ def torch_lib_dir() -> str | None:
     return None
 
 
+def _buildid_module():
+    spec = importlib.util.spec_from_file_location("_te_buildid", os.path.join(PKG_DIR, "_buildid.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _newer(a: str, b: str) -> bool:
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
@@ -66,14 +74,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # measurement builds only (benchmarks/): TE_BUILD_DEFINES="TE_X6_STUDY" adds -D flags and forces a rebuild
     extra = ["-D" + d for d in os.environ.get("TE_BUILD_DEFINES", "").split() if d]
     force = force or bool(extra)
+    # provenance: a content hash of every source + the flags, baked into te_api.o (te_build_id()) and
+    # checked by _lib.load() against the tree.  A changed id recompiles te_api.hip even when its own mtime says "fresh".
+    bid = _buildid_module().build_id([*CXXFLAGS, *extra])
+    stamp = os.path.join(OBJ_DIR, "build_id.txt")
+    old_bid = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if old_bid == bid and os.path.exists(LIB_PATH) and not force:
+        return LIB_PATH          # same sources, same flags: up to date whatever the mtimes of a copied tree say
     objs, rebuilt = [], False
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(h, o) for h in headers):
+        stale_id = src == "te_api.hip" and old_bid != bid
+        if force or stale_id or _newer(s, o) or any(_newer(h, o) for h in headers):
             cmd = [hipcc, *CXXFLAGS, *extra, "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
+            if src == "te_api.hip":
+                cmd.insert(-4, f'-DTE_BUILD_ID="{bid}"')
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -95,6 +113,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout)
+    with open(stamp, "w") as f:
+        f.write(bid + "\n")
     return LIB_PATH
 
 

@@ -3,7 +3,12 @@
 
 #include <string.h>
 
-extern "C" int te_version(void) { return 501; /* 0.5.1: round 5 -- study schedules out of the shipped build (te_x6_study_build); GELU producers that emit operand planes */ }
+extern "C" int te_version(void) { return 600; /* 0.6.0: round 6 -- te_build_id() */ }
+
+#ifndef TE_BUILD_ID
+#define TE_BUILD_ID "unstamped"      // a build that did not go through build.py: _lib.load() refuses it
+#endif
+extern "C" const char* te_build_id(void) { return TE_BUILD_ID; }
 
 extern "C" int te_x6_study_build(void) {
   int bits = 0;
