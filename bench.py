@@ -541,6 +541,8 @@ def cpu_baseline(args, wl):
         what = "our CPU forward/backward + the CPU oracle's relprop (no reference checkout or stage on this host)"
 
     ref_maps = {}      # input index -> the map this leg computed (BASELINE.json's metric: "max |delta| vs CPU ref")
+    maps_by_threads = {}   # threads -> {input index -> map}: the same inputs under another thread count = another GEMM
+    #                        summation order on the host: how far the reference moves from ITSELF (the parity block's floor)
 
     def leg(threads, n_maps):
         torch.set_num_threads(threads)
@@ -551,6 +553,7 @@ def cpu_baseline(args, wl):
                 m = run(i % n_in)
             times.append(time.perf_counter() - t0)
             ref_maps.setdefault(i % n_in, m.detach().float().reshape(1, -1).clone())
+            maps_by_threads.setdefault(threads, {}).setdefault(i % n_in, m.detach().float().reshape(1, -1).clone())
             log(f"cpu_baseline({kind}, {threads} threads) {wl.noun[:-1]} {i}: {times[-1]:.2f} s")
         times = sorted(times[1:])
         return times[len(times) // 2]
@@ -565,6 +568,10 @@ def cpu_baseline(args, wl):
     if wl.name in ("vit_b16_224", "sweep50k"):
         one = leg(1, 2) if cores > 1 else legs[cores]
     torch.set_num_threads(cores)
+    first = next(iter(maps_by_threads))             # the all-cores leg: what ref_maps holds
+    self_rows = [{"sample": i, "threads": f"{first} vs {t}", **_map_stats(m, maps_by_threads[first][i])}
+                 for t, d in maps_by_threads.items() if t != first for i, m in sorted(d.items()) if i in maps_by_threads[first]]
+    ref_maps["self"] = self_rows
     return ref_maps, {"value": 1.0 / legs[best], "unit": wl.unit, "cores": best, "kind": kind,
             "cpu_model": cpu_model_string(), "usable_cores": cores,
             "seconds_per_unit_by_threads": {str(k): round(v, 4) for k, v in sorted(legs.items())},
@@ -592,8 +599,9 @@ def _worst(rows, vs, note):
     return out
 
 
-def parity_block(args, wl, gpu_maps, ref_maps):
-    """The accuracy half of BASELINE.json's metric ("max |delta| vs CPU ref"), OUTSIDE the timed region:
+def cpu_baseline_parity(args, wl, gpu_maps, ref_maps):
+    """Second half of the cpu_baseline leg: the accuracy half of BASELINE.json's metric ("max |delta| vs CPU ref"), OUTSIDE
+    the timed region, after the line's throughput is final:
 
       vs_reference_cpu   the maps of the timed region's last step against the maps the cpu_baseline leg computed for the
                          same inputs (images / sequences 0 .. cpu_maps of rank 0's batch, the same weights): the whole
@@ -612,10 +620,19 @@ def parity_block(args, wl, gpu_maps, ref_maps):
                                       "normalisation; rel_linf = raw / max |ref|; each the worst over the samples listed"}
     B = wl.B
     got = gpu_maps.detach().float().cpu()
+    self_rows = ref_maps.pop("self", []) if ref_maps else []
     if ref_maps:
         rows = [{"sample": i, **_map_stats(got[i], m)} for i, m in sorted(ref_maps.items()) if i < B]
         out["vs_reference_cpu"] = _worst(rows, "reference CPU", "whole pipeline vs the reference's generate_LRP on the host "
                                          "cores (the cpu_baseline leg's own maps): different producers, see DESIGN.md section 4")
+        if self_rows:
+            keys = ("raw_max_abs", "normalised_max_abs", "rel_linf")
+            out["reference_cpu_vs_itself"] = {
+                **{k: max(r[k] for r in self_rows) for k in keys}, "samples": len(self_rows),
+                "note": "the reference's own maps of the same inputs under another torch thread count (another fp32 GEMM summation "
+                        "order on the same host): the floor under vs_reference_cpu for these random-init weights",
+                "per_sample": [{"sample": r["sample"], "threads": r["threads"], **{k: float(f"{r[k]:.3e}") for k in keys}}
+                               for r in self_rows]}
     is_vit = wl.name.startswith("vit")
     # one more eager, serial step: its module caches are what the oracle reads; its maps must equal the replayed step's
     eager = wl.eager_serial(*wl.inputs).detach().clone()
@@ -798,12 +815,18 @@ def main():
         maps = step(eager=probe and not args.no_roofline, k=k)
     host_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (GPU still running)
     join()
+    t_compute = t_gather0 = None
+    if world > 1:      # per-rank readiness figures: this rank's own compute time, then the gather's wall time
+        torch.cuda.synchronize()
+        t_gather0 = time.perf_counter()
+        t_compute = t_gather0 - t0
     if wl.sweep:     # ONE collective for the whole sweep: every rank's [K * B, 196] block, in global order
         n_sweep = SWEEP_IMAGES if (not args.batch and args.steps == -(-SWEEP_IMAGES // SWEEP_GLOBAL_BATCH)) else world * wl.sweep_local
         gathered = parallel.gather_maps(sweep_maps, n_sweep)
     else:
         gathered = parallel.gather_maps(maps, world * B)
     torch.cuda.synchronize()
+    t_gather = (time.perf_counter() - t_gather0) if t_gather0 is not None else None
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -811,12 +834,20 @@ def main():
     log(f"timed {args.steps} steps: {elapsed:.3f} s (host enqueue {host_enqueue:.3f} s)")
     timer.enabled = False
     ops.KERNEL_TIMER = None
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        mine = torch.tensor([t_compute, t_gather, float(wl.sweep_local if wl.sweep else B * args.steps)], dtype=torch.float64,
+                            device=dev)
         if torch.distributed.get_backend() == "gloo":
-            t = t.cpu()
+            t, mine = t.cpu(), mine.cpu()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        every = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)        # (after the timed region: bookkeeping, not part of the data path)
+        per_rank = [{"rank": r, "units": int(v[2]), "compute_s": round(float(v[0]), 4),
+                     "units_per_s": round(float(v[2] / v[0]), 2), "gather_ms": round(float(v[1]) * 1e3, 3)}
+                    for r, v in enumerate(every)]
     n_units = n_sweep if wl.sweep else world * B * args.steps          # what the timed region explained, all ranks
     gpu_maps = None if wl.sweep else maps.detach().clone()             # (a graph's static output: kept before anything re-runs)
     assert gathered.shape == ((n_sweep if wl.sweep else world * B), wl.out_cols) and torch.isfinite(gathered).all()
@@ -889,7 +920,13 @@ def main():
                                    f"({fused_note}) + fp32 relprop/head-mean/rollout HIP kernels"
                                    f"{' (Linear rules: fp32 operands as three bf16 planes on bf16 MFMAs)' if args.linear == 'x6' else ''} (BASELINE.json "
                                    f"configs[{idx}], sharded by sample)",
-                       "batch_per_gpu": B, "global_batch": world * B, "tokens": wl.tokens, "blocks": wl.blocks,
+                       "batch_per_gpu": B, "global_batch": world * B, "world": world, "tokens": wl.tokens, "blocks": wl.blocks,
+                       **({"per_rank": per_rank,
+                           "per_rank_note": "compute_s = the rank's own wall time from the common start to its last kernel (synchronised), "
+                                            "units_per_s = its units / compute_s, gather_ms = wall time of the single all_gather "
+                                            "of the maps (includes waiting for the slowest rank); value = all units / the slowest "
+                                            "rank's whole timed region",
+                           "dist_backend": torch.distributed.get_backend()} if per_rank else {}),
                        **({"sweep_images": n_units, "sweep_last_batch_per_rank": wl.sweep_inputs[-1].shape[0],
                            "sweep_note": "parallel.sweep_layout: images keyed by GLOBAL index (rank r owns the "
                            "contiguous block r of the sweep, walked in batches of 256 / ranks; the whole sweep ends in one short "
@@ -1004,7 +1041,7 @@ def main():
         line["cpu_baseline"] = base
         if world == 1 and gpu_maps is not None and args.parity != "off":
             try:
-                line["parity"] = parity_block(args, wl, gpu_maps, ref_maps)
+                line["parity"] = cpu_baseline_parity(args, wl, gpu_maps, ref_maps)
             except Exception as exc:      # the line must still be printed: the failure is part of it
                 line["parity"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)

@@ -19,9 +19,16 @@ if [[ $PART == *A* ]]; then
   ( timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=5 --maxfail=6 2>&1 | tail -40 ) > gpurun_out/tests_full.log
   ( timeout 200 python __graft_entry__.py smoke 2>&1 | tail -5 ) > gpurun_out/smoke.log
   ( timeout 300 python bench.py --steps 20 > gpurun_out/bench_b64.json 2> gpurun_out/bench_b64.err )
+  # the multi-rank path on the one GPU (rig: gloo, every rank on device 0), so that `--gpus 8` cannot rot between rounds:
+  # the driver's own invocation shape (headline configuration, torch.distributed.run, 8 ranks) and the self-launched sweep
+  ( TE_DIST_BACKEND=gloo TE_DEVICE_OVERRIDE=0 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+      --master-port 29533 bench.py --gpus 8 --batch 8 --steps 2 --warmup 1 --cpu-baseline off > gpurun_out/bench_8rank_rig.json 2> gpurun_out/bench_8rank_rig.err )
+  ( TE_DIST_BACKEND=gloo TE_DEVICE_OVERRIDE=0 timeout 300 python bench.py --gpus 8 --config sweep50k --batch 4 --steps 2 --warmup 1 --cpu-baseline off \
+      > gpurun_out/bench_sweep50k_8rank_rig.json 2> gpurun_out/bench_sweep50k_8rank_rig.err )
   echo "=== tests ==="; tail -15 gpurun_out/tests_full.log
   echo "=== smoke ==="; cat gpurun_out/smoke.log
   echo "=== bench ==="; cut -c1-400 gpurun_out/bench_b64.json; tail -4 gpurun_out/bench_b64.err
+  echo "=== 8-rank rig lines ==="; cut -c1-300 gpurun_out/bench_8rank_rig.json; tail -3 gpurun_out/bench_8rank_rig.err; cut -c1-300 gpurun_out/bench_sweep50k_8rank_rig.json; tail -3 gpurun_out/bench_sweep50k_8rank_rig.err
 fi
 if [[ $PART == *B* ]]; then
   if [ -n "$RERUN_TESTS" ]; then      # (a second look at tests changed after part A)
@@ -30,8 +37,6 @@ if [[ $PART == *B* ]]; then
   fi
   prof prof --steps 10
   prof prof_serial --steps 10 --overlap-backward off --inflight 1
-  ( TE_DIST_BACKEND=gloo TE_DEVICE_OVERRIDE=0 timeout 300 python bench.py --gpus 8 --config sweep50k --batch 4 --steps 2 --warmup 1 --cpu-baseline off \
-      > gpurun_out/bench_sweep50k_8rank_rig.json 2> gpurun_out/bench_sweep50k_8rank_rig.err )
   ( TE_DIST_BACKEND=gloo TE_DEVICE_OVERRIDE=0 timeout 200 python bench.py --gpus 2 --batch 16 --steps 2 --warmup 1 --cpu-baseline off \
       > gpurun_out/bench_2rank_rig.json 2> gpurun_out/bench_2rank_rig.err )
   for cfg in vit_l16_384 bert_base_512; do

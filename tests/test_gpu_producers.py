@@ -421,7 +421,9 @@ def test_mlp_block_gelu_hands_planes_to_its_neighbours():
     """vit.Mlp (ViT_LRP.py:57-74: fc1 -> GELU -> fc2) with the Linear layers on the x6 kernels: the activation emits fc2's
     operand planes in its forward pass and fc1's input-gradient operand in its backward pass (producers._Gelu) -- output,
     input gradient and the relprop result are bitwise those of the separate split passes (ops.X6_FUSE_GELU = False), the
-    fused kernels are the ones that ran, and a second consumer of the hidden gradient would read NaN, never stale memory."""
+    fused kernels are the ones that ran.  The backward hand-off is an OPT-IN of the caller that owns the backward pass
+    (ops.gelu_backward_plane_handoff): under a plain forward the hidden gradient is the real fp32 tensor for
+    every consumer (autograd.grad / retain_grad / hooks); inside the context it is a NaN placeholder for anyone but fc1."""
     from transformer_explainability_amd import ops, producers, rules, vit
     d = dev()
     torch.manual_seed(3)
@@ -447,7 +449,8 @@ def test_mlp_block_gelu_hands_planes_to_its_neighbours():
         outs = []
         for fuse in (False, True):
             ops.X6_FUSE_GELU = fuse
-            y = mlp(x)
+            with ops.gelu_backward_plane_handoff():      # what LRP.generate_LRP / Generator.generate_LRP do for their forward
+                y = mlp(x)
             (dx,) = torch.autograd.grad(y, x, g)
             cam = mlp.relprop(R, alpha=1.0)
             outs.append((y.detach().clone(), dx.clone(), cam.clone()))
@@ -457,14 +460,43 @@ def test_mlp_block_gelu_hands_planes_to_its_neighbours():
         for a, b in zip(*outs):
             assert torch.equal(a, b)
         assert torch.isfinite(outs[1][1]).all()
-        # the placeholder autograd carries between the two nodes: NaN for anyone but fc1's input-gradient product
+        ops.X6_FUSE_GELU = True
+        gh = rnd((4, 197, 3072), 98).to(d)
+        # plain forward (no opt-in): standard autograd semantics for the hidden activation -- the real gradient, for
+        # autograd.grad, retain_grad and a tensor hook alike; the whole-block gradient is still bitwise the fused one
+        ops.X6_FUSE_GELU = False
+        h0 = mlp.fc1(x)
+        (dh_ref,) = torch.autograd.grad(mlp.act(h0), h0, gh)
         ops.X6_FUSE_GELU = True
         h = mlp.fc1(x)
+        h.retain_grad()
+        seen = []
+        h.register_hook(lambda t: seen.append(t.detach().clone()))
         a = mlp.act(h)
-        (dh,) = torch.autograd.grad(a, h, rnd((4, 197, 3072), 98).to(d))
+        (dh,) = torch.autograd.grad(a, h, gh, retain_graph=True)
+        assert torch.isfinite(dh).all() and torch.equal(dh, dh_ref)
+        y2 = mlp.fc2(a)
+        (dx2,) = torch.autograd.grad(y2, x, g)
+        assert torch.equal(dx2, outs[1][1]) and len(seen) == 2 and all(torch.isfinite(t).all() for t in seen)
+        assert "dy_planes_from_consumer" not in rules.x6_cache(mlp.fc1)
+        assert calls["bwd"] == 1                         # the plane-emitting backward did not run outside the context
+        # inside the context the placeholder between the two nodes is NaN for anyone but fc1's input-gradient product
+        with ops.gelu_backward_plane_handoff():
+            h = mlp.fc1(x)
+            a = mlp.act(h)
+        (dh,) = torch.autograd.grad(a, h, gh)
         assert dh.shape == h.shape and not any(dh.stride()) and torch.isnan(dh).all()
         rules.x6_cache(mlp.fc1).pop("dy_planes_from_consumer", None)
         rules.x6_cache(mlp.fc2).pop("x_planes_from_producer", None)
+        # the forward planes are held together with the tensor they were split from: a consumer that receives another
+        # tensor falls back to its own split pass (and the entry is dropped)
+        a = mlp.act(mlp.fc1(x))
+        assert "x_planes_from_producer" in rules.x6_cache(mlp.fc2)
+        assert rules.x6_cache(mlp.fc2)["x_planes_from_producer"][3] is a or \
+            rules.x6_cache(mlp.fc2)["x_planes_from_producer"][3].data_ptr() == a.data_ptr()
+        other = a.detach().clone()
+        y3 = mlp.fc2(other)
+        assert "x_planes_from_producer" not in rules.x6_cache(mlp.fc2) and torch.equal(y3, mlp.fc2(a.detach()))
     finally:
         ops.gelu_forward_planes, ops.gelu_backward_planes = f0, b0
         ops.USE_FUSED_PRODUCERS, ops.X6_GEMM, ops.X6_FUSE_GELU = was

@@ -73,7 +73,7 @@ def test_bench_uses_the_oracle_only_in_its_cpu_baseline_leg():
     path = os.path.join(ROOT, "bench.py")
     with open(path) as f:
         tree = ast.parse(f.read(), path)
-    allowed = {"cpu_baseline"}
+    allowed = {"cpu_baseline", "cpu_baseline_parity"}      # the leg's timing half and its parity half (the checker, checking)
     bad = []
 
     def visit(node, fn):
@@ -91,7 +91,7 @@ def test_bench_uses_the_oracle_only_in_its_cpu_baseline_leg():
     # and the timed region (main) never calls cpu_baseline before the line's throughput is computed
     main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
     calls = [n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)
-             and n.func.id == "cpu_baseline"]
+             and n.func.id in ("cpu_baseline", "cpu_baseline_parity")]
     value_line = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Assign) and any(
         isinstance(t, ast.Name) and t.id == "value" for t in n.targets))
     assert calls and min(calls) > value_line, (calls, value_line)

@@ -107,6 +107,47 @@ def test_hdf5_backend_round_trip(tmp_path):
         ResultsStore(str(tmp_path / "x"), 7, (3, 32, 32), (1, 32, 32), 0, 3, backend="hdf5")
 
 
+def test_hdf5_backend_call_sequence_against_stand_in(tmp_path):
+    """Where h5py is absent (this image), the hdf5 backend's CALLS are still exercised -- against the minimal h5py stand-in
+    of tests/refscripts/stubs (an .npz container behind h5py's File / create_dataset / resize / slicing API; NOT libhdf5, so
+    this says nothing about the on-disk format): ResultsStore(backend="hdf5") writes through it, then the REFERENCE'S OWN
+    reader (dataset/expl_hdf5.py:8-31, from the stage) and this package's ImagenetResults read the same items back."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stage = os.path.join(root, "oracle", "_ref")
+    if not os.path.exists(os.path.join(stage, "dataset", "expl_hdf5.py")):
+        pytest.skip("no staged reference reader (oracle/_ref/dataset/expl_hdf5.py)")
+    code = r"""
+import sys, numpy as np, torch, importlib.util
+import h5py
+assert h5py.__version__.endswith("stub")
+import transformer_explainability_amd as te
+from transformer_explainability_amd.sweep import ImagenetResults, ResultsStore
+d = sys.argv[1]
+g = torch.Generator().manual_seed(0)
+img, vis, tgt = torch.rand(7, 3, 8, 8, generator=g), torch.rand(7, 1, 8, 8, generator=g), torch.arange(7) * 3
+with ResultsStore(d, 9, (3, 8, 8), (1, 8, 8), backend="hdf5") as st:      # sized for 9, 7 appended: close() trims
+    st.append(img[:4], tgt[:4], vis[:4])
+    st.append(img[4:], tgt[4:], vis[4:])
+spec = importlib.util.spec_from_file_location("ref_expl_hdf5", sys.argv[2])
+ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+for cls in (ref.ImagenetResults, ImagenetResults):
+    ds = cls(d)
+    assert len(ds) == 7, len(ds)
+    for i in (0, 3, 6):
+        a, v, t = ds[i]
+        assert torch.equal(a, img[i]) and torch.equal(v, vis[i]) and int(t) == int(tgt[i]) and t.dtype == torch.int64
+print("ok")
+"""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "tests", "refscripts", "stubs"), root])
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path), os.path.join(stage, "dataset", "expl_hdf5.py")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
 def test_store_guards(tmp_path):
     from transformer_explainability_amd.sweep import ImagenetResults, ResultsStore, SaliencySweep
     with pytest.raises(ValueError):

@@ -26,14 +26,16 @@ class VisionTransformer(_vit.VisionTransformer):
 
 
 def vit_base_patch16_224(pretrained=False, **kwargs):
-    if pretrained:
-        raise RuntimeError("no network: load a checkpoint with model.load_state_dict(...)")
-    return VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
-                             block_norm_eps=1e-6, final_norm_eps=1e-6, **kwargs)
+    model = VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                              block_norm_eps=1e-6, final_norm_eps=1e-6, **kwargs)
+    if pretrained:       # ViT_new.py:222-230: the same checkpoint as the LRP-instrumented model, from the torch hub cache
+        _vit.load_pretrained_weights(model, _vit.PRETRAINED_URLS["vit_base_patch16_224"], patch_size=16)
+    return model
 
 
 def vit_large_patch16_224(pretrained=False, **kwargs):
+    model = VisionTransformer(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
+                              block_norm_eps=1e-6, final_norm_eps=1e-6, **kwargs)
     if pretrained:
-        raise RuntimeError("no network: load a checkpoint with model.load_state_dict(...)")
-    return VisionTransformer(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
-                             block_norm_eps=1e-6, final_norm_eps=1e-6, **kwargs)
+        _vit.load_pretrained_weights(model, _vit.PRETRAINED_URLS["vit_large_patch16_224"], patch_size=16)
+    return model

@@ -90,7 +90,8 @@ class LRP:
         ops.x6_raise_if_failed(next(self.model.parameters()).device)
 
     def _generate(self, input, index, method, is_ablation, start_layer):
-        output = self.model(input)
+        with ops.gelu_backward_plane_handoff():      # this call drives the backward pass itself (attention tensors only)
+            output = self.model(input)
         kwargs = {"alpha": 1}
         one_hot = _one_hot(output, index)
         loss = torch.sum(one_hot * output)
@@ -143,7 +144,8 @@ class Baselines:
 
     def generate_cam_attn(self, input, index=None):
         """attention GradCAM of the last block (:50-72): per-head gradient mean x attention, class-token row."""
-        output = self.model(input, register_hook=True)
+        with ops.gelu_backward_plane_handoff():      # this call drives the backward pass itself (attention tensors only)
+            output = self.model(input, register_hook=True)
         one_hot = _one_hot(output, index)
         last = self.model.blocks[-1].attn
         (grad,) = torch.autograd.grad(torch.sum(one_hot * output), [last.get_attention_map()])
@@ -302,7 +304,8 @@ class Generator:
     def _explain(self, input_ids, attention_mask, index, lowest_layer=0):
         """forward, attention-gradient backward, relprop.  With prune=True only the layers >= lowest_layer are served."""
         from .rules import StopRelprop
-        output = self.model(input_ids=input_ids, attention_mask=attention_mask)[0]
+        with ops.gelu_backward_plane_handoff():      # this call drives the backward pass itself (attention tensors only)
+            output = self.model(input_ids=input_ids, attention_mask=attention_mask)[0]
         one_hot = _one_hot(output, index)
         loss = torch.sum(one_hot * output)
         layers = self.model.bert.encoder.layer
@@ -365,7 +368,8 @@ class Generator:
     def generate_full_lrp(self, input_ids, attention_mask, index=None):
         """ExplanationGenerator.py:86-106: relevance propagated to the encoder input, summed over the hidden
         dimension, CLS slot zeroed."""
-        output = self.model(input_ids=input_ids, attention_mask=attention_mask)[0]
+        with ops.gelu_backward_plane_handoff():      # this call drives the backward pass itself (attention tensors only)
+            output = self.model(input_ids=input_ids, attention_mask=attention_mask)[0]
         one_hot = _one_hot(output, index)
         layers = self.model.bert.encoder.layer
         # relprop reads the attention gradients nowhere, but the reference runs the backward first (:100-101) and the

@@ -373,9 +373,14 @@ def gemm_x6(X: Tensor, w_planes: Tensor, bias: Optional[Tensor], M: int, timer_n
         xs = x_planes
         if xs is None and keep_abs is not None:
             hit = keep_abs.pop("x_planes_from_producer", None)
-            if hit is not None and hit[0] == _x_abs_key(X, T, K):
+            # the entry HOLDS the tensor the planes were split from (hit[3]): while the entry exists that address cannot be
+            # recycled for a new tensor that would meet the key by accident
+            if hit is not None and hit[0] == _x_abs_key(X, T, K) and hit[3].data_ptr() == X.data_ptr():
                 xs, x_bytes = hit[1], 6.0 * T * K
                 keep_abs["x_abs_planes"] = (hit[0], hit[2])
+        if xs is not None and xs.numel() * xs.element_size() < lib.te_linear_x6_planes_bytes(T, K):
+            raise _lib.TeError(f"gemm_x6: the operand planes handed in hold {xs.numel() * xs.element_size()} bytes, "
+                               f"[{T}, {K}] needs {lib.te_linear_x6_planes_bytes(T, K)}")
         with _timed(timer_name, 12.0 * T * K * M, x_bytes + 6.0 * K * M + 4.0 * T * M):
             if (xs is None and keep_abs is not None and USE_LINEAR_X6 and X6_KEEP_ABS
                     and lib.te_linear_relprop_x6_supported(T, K, M)):
@@ -775,6 +780,32 @@ def gelu_forward(x: Tensor) -> Tensor:
 
 
 X6_FUSE_GELU = os.environ.get("TE_X6_FUSE_GELU", "1") not in ("", "0")     # measurement switch: GELU emits operand planes
+
+
+# The backward hand-off (GELU-backward writes the planes of the hidden gradient into the producing Linear's cache and autograd
+# carries a NaN placeholder instead of the fp32 gradient) is only sound where the WHOLE backward graph is known: nobody but
+# that Linear's backward may consume the gradient (no tensor hook / retain_grad / autograd.grad on the hidden activation, no
+# second consumer).  It is therefore OFF unless the caller that owns forward + backward opts in for its own forward pass
+# (ADVICE r5): LRP / Baselines / Generator do, inside ``gelu_backward_plane_handoff()``; a plain ``model(x)`` never does.
+_GELU_BWD_HANDOFF = 0
+
+
+class gelu_backward_plane_handoff:
+    """Context manager for a forward pass whose backward the caller drives itself with torch.autograd.grad towards attention
+    tensors only (generators.py).  Re-entrant; the decision is taken at forward time (per GELU node)."""
+
+    def __enter__(self):
+        global _GELU_BWD_HANDOFF
+        _GELU_BWD_HANDOFF += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _GELU_BWD_HANDOFF
+        _GELU_BWD_HANDOFF -= 1
+
+
+def gelu_backward_handoff_active() -> bool:
+    return _GELU_BWD_HANDOFF > 0
 
 
 def gelu_planes_supported(x: Tensor) -> bool:

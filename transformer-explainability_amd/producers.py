@@ -69,7 +69,10 @@ class _Gelu(torch.autograd.Function):
                 on gemm_x6 (producers.linear marks its output): the gradient leaves this node as planes in that dict
                 ("dy_planes_from_consumer") and as a zero-stride NaN placeholder in autograd's hands -- _Linear.backward
                 recognises the placeholder by its address and never reads it; anything else that consumed it would read
-                NaN, not stale memory."""
+                NaN, not stale memory.  ONLY inside ``ops.gelu_backward_plane_handoff()`` (round 6): the
+                generators of this package, which drive the backward pass themselves towards attention tensors only, opt
+                in for their own forward pass; under a plain ``model(x)`` the node returns the real fp32 gradient, so
+                ``autograd.grad(out, h)``, ``h.retain_grad()``, tensor hooks and second consumers see standard autograd."""
 
     @staticmethod
     def forward(ctx, x, feeds, source):
@@ -78,7 +81,7 @@ class _Gelu(torch.autograd.Function):
         if feeds is not None:
             y, xs, xa = ops.gelu_forward_planes(x)
             K = y.shape[-1]
-            feeds["x_planes_from_producer"] = (ops._x_abs_key(y, y.numel() // K, K), xs, xa)
+            feeds["x_planes_from_producer"] = (ops._x_abs_key(y, y.numel() // K, K), xs, xa, y)
             return y
         return ops.gelu_forward(x)
 
@@ -167,5 +170,8 @@ def gelu(x, consumer=None, consumer_cache=None):
             if (ops.USE_LINEAR_X6 and ops.X6_KEEP_ABS
                     and ops.linear_relprop_x6_supported(x.numel() // in_f, in_f, out_f)):
                 feeds = consumer_cache
-        source = getattr(x, "_te_bwd_x6_cache", None)
+        if ops.gelu_backward_handoff_active():     # opt-in of the caller that owns the backward pass (ops.py)
+            source = getattr(x, "_te_bwd_x6_cache", None)
+    if feeds is None and consumer_cache is not None:
+        consumer_cache.pop("x_planes_from_producer", None)      # nothing of an earlier call may wait there for this one's output
     return _Gelu.apply(x, feeds, source)

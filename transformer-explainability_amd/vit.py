@@ -93,6 +93,45 @@ class _FusedAttention(torch.autograd.Function):
         return (None if stop else d_qkv), None, None, None
 
 
+# the checkpoints the reference's factories fetch (ViT_LRP.py:24-36, 428-435 -- the same URLs in ViT_new.py / ViT_orig_LRP.py)
+PRETRAINED_URLS = {
+    "vit_base_patch16_224": "https://github.com/rwightman/pytorch-image-models/releases/download/v0.1-vitjx/"
+                            "jx_vit_base_p16_224-80ecf9dd.pth",
+    "vit_large_patch16_224": "https://github.com/rwightman/pytorch-image-models/releases/download/v0.1-vitjx/"
+                             "jx_vit_large_p16_224-4ee7a4dc.pth",
+    "deit_base_patch16_224": "https://dl.fbaipublicfiles.com/deit/deit_base_patch16_224-b5f2ef4d.pth",
+}
+
+
+def load_pretrained_weights(model, url, patch_size=16, key=None):
+    """``pretrained=True`` of the reference's factories (helpers.py:87-150 ``load_pretrained`` -> ``model_zoo.load_url``;
+    DeiT: ``torch.hub.load_state_dict_from_url``, ViT_LRP.py:432): the checkpoint comes from the torch hub cache
+    (``$TORCH_HOME/hub/checkpoints/<file name of the URL>``) and is downloaded only if it is not there -- on a host without
+    a network that means: put the file there once.  Same post-processing as the reference: a linear patch-embedding
+    weight is reshaped to the convolution's [C, 3, p, p] (``_conv_filter``, ViT_LRP.py:399-406); a classifier of another
+    width than the model's is dropped and the rest loaded non-strictly (helpers.py:143-147)."""
+    import os
+    name = os.path.basename(url)
+    try:
+        state = torch.hub.load_state_dict_from_url(url, map_location="cpu", progress=False)
+    except Exception as exc:       # urllib's errors on a host without a network
+        where = os.path.join(torch.hub.get_dir(), "checkpoints", name)
+        raise RuntimeError(f"pretrained=True: {name} is not in the torch hub cache and could not be downloaded "
+                           f"({type(exc).__name__}: {exc}); place the checkpoint at {where}") from exc
+    if key is not None:
+        state = state[key]
+    state = dict(state)
+    w = state.get("patch_embed.proj.weight")
+    if w is not None and w.dim() == 2:
+        state["patch_embed.proj.weight"] = w.reshape(w.shape[0], 3, patch_size, patch_size)
+    strict = True
+    if "head.weight" in state and state["head.weight"].shape[0] != model.head.weight.shape[0]:
+        del state["head.weight"], state["head.bias"]
+        strict = False
+    model.load_state_dict(state, strict=strict)
+    return model
+
+
 def make_vit_module(L):
     """Build the model classes over a rule namespace ``L`` (rules for 'ours', rules_lrp for 'lrp')."""
 
@@ -424,19 +463,25 @@ def make_vit_module(L):
             return None   # unknown method: the reference falls through silently
 
     def vit_base_patch16_224(pretrained=False, **kwargs):
+        model = VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                                  **kwargs)
         if pretrained:
-            raise RuntimeError("no network: load a checkpoint with model.load_state_dict(...)")
-        return VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
-                                 **kwargs)
+            load_pretrained_weights(model, PRETRAINED_URLS["vit_base_patch16_224"], patch_size=16)
+        return model
 
     def vit_large_patch16_224(pretrained=False, **kwargs):
+        model = VisionTransformer(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
+                                  **kwargs)
         if pretrained:
-            raise RuntimeError("no network: load a checkpoint with model.load_state_dict(...)")
-        return VisionTransformer(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
-                                 **kwargs)
+            load_pretrained_weights(model, PRETRAINED_URLS["vit_large_patch16_224"], patch_size=16)
+        return model
 
     def deit_base_patch16_224(pretrained=False, **kwargs):
-        return vit_base_patch16_224(pretrained=pretrained, **kwargs)
+        model = VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                                  **kwargs)
+        if pretrained:
+            load_pretrained_weights(model, PRETRAINED_URLS["deit_base_patch16_224"], patch_size=16, key="model")
+        return model
 
     ns = dict(Mlp=Mlp, Attention=Attention, Block=Block, PatchEmbed=PatchEmbed, VisionTransformer=VisionTransformer,
               vit_base_patch16_224=vit_base_patch16_224, vit_large_patch16_224=vit_large_patch16_224,
