@@ -471,6 +471,7 @@ def cpu_baseline(args, wl):
     from oracle import ref_harness as rh
     cores = usable_cores()
     kind = "reference" if (rh.reference_available() and args.cpu_baseline != "port") else "port"
+    run64 = None
     log(f"cpu_baseline: kind {kind} ({rh.reference_origin()}), {cores} usable cores (os.cpu_count() = {os.cpu_count()}), "
         f"{cpu_model_string()}")
     n_in = max(args.cpu_maps, 2) + 1
@@ -486,14 +487,22 @@ def cpu_baseline(args, wl):
         if is_vit:
             mods = rh.load_reference_vit()
             ref_mod = mods["ViT_LRP"] if wl.rules == "ours" else mods["ViT_orig_LRP"]
-            if wl.name in ("vit_b16_224", "sweep50k"):
-                model = ref_mod.vit_base_patch16_224(pretrained=False).eval()
-            else:
-                model = ref_mod.vit_large_patch16_224(pretrained=False, img_size=384).eval()
-            model.load_state_dict(wl.cpu_state)
+            def fresh():
+                if wl.name in ("vit_b16_224", "sweep50k"):
+                    m_ = ref_mod.vit_base_patch16_224(pretrained=False).eval()
+                else:
+                    m_ = ref_mod.vit_large_patch16_224(pretrained=False, img_size=384).eval()
+                m_.load_state_dict(wl.cpu_state)
+                return m_
+            model = fresh()
             gen = mods["gen"].LRP(model)
             meth = "transformer_attribution" if wl.rules == "ours" else "grad"
             run = lambda i: gen.generate_LRP(xs[i:i + 1], method=meth, start_layer=wl.start_layer)    # noqa: E731
+
+            def run64(i, _cache=[]):      # the same reference code and weights evaluated in fp64 (parity block's yardstick)
+                if not _cache:
+                    _cache.append(mods["gen"].LRP(fresh().double()))
+                return _cache[0].generate_LRP(xs[i:i + 1].double(), method=meth, start_layer=wl.start_layer)
             what = (f"reference LRP.generate_LRP over {'ViT_LRP' if wl.rules == 'ours' else 'ViT_orig_LRP'} "
                     f"(baselines/ViT/ViT_explanation_generator.py:25-41, method {meth})")
         else:
@@ -501,11 +510,20 @@ def cpu_baseline(args, wl):
             from transformers import BertConfig
             cfg = BertConfig(num_labels=2)
             cfg.return_dict = False
-            model = mods["cls"].BertForSequenceClassification(cfg).eval()
-            model.load_state_dict(wl.cpu_state, strict=False)
+            def fresh():
+                m_ = mods["cls"].BertForSequenceClassification(cfg).eval()
+                m_.load_state_dict(wl.cpu_state, strict=False)
+                return m_
+            model = fresh()
             gen = mods["gen"].Generator(model)
             run = lambda i: gen.generate_LRP(input_ids=xs[i:i + 1], attention_mask=ms[i:i + 1],   # noqa: E731
                                              start_layer=wl.start_layer)
+
+            def run64(i, _cache=[]):
+                if not _cache:
+                    _cache.append(mods["gen"].Generator(fresh().double()))
+                return _cache[0].generate_LRP(input_ids=xs[i:i + 1], attention_mask=ms[i:i + 1].double(),
+                                              start_layer=wl.start_layer)
             what = "reference Generator.generate_LRP (BERT_explainability/modules/BERT/ExplanationGenerator.py:28-59)"
     else:
         from oracle import relprop_oracle as O
@@ -572,6 +590,20 @@ def cpu_baseline(args, wl):
     self_rows = [{"sample": i, "threads": f"{first} vs {t}", **_map_stats(m, maps_by_threads[first][i])}
                  for t, d in maps_by_threads.items() if t != first for i, m in sorted(d.items()) if i in maps_by_threads[first]]
     ref_maps["self"] = self_rows
+    # the reference in fp64 on the first inputs (outside every timing): how far its own fp32 map is from the exact one
+    ref64 = {}
+    if run64 is not None and args.parity != "off":
+        n64 = 3 if wl.name in ("vit_b16_224", "sweep50k") else 2
+        for i in range(min(n64, n_in)):
+            t0 = time.perf_counter()
+            try:
+                with rh.reference_on_cpu():
+                    ref64[i] = run64(i).detach().double().reshape(1, -1).clone()
+            except Exception as exc:      # (a reference module that does not survive .double(): the block says so)
+                ref64 = {"error": f"{type(exc).__name__}: {exc}"}
+                break
+            log(f"cpu_baseline: reference in fp64, {wl.noun[:-1]} {i}: {time.perf_counter() - t0:.2f} s")
+    ref_maps["ref64"] = ref64
     return ref_maps, {"value": 1.0 / legs[best], "unit": wl.unit, "cores": best, "kind": kind,
             "cpu_model": cpu_model_string(), "usable_cores": cores,
             "seconds_per_unit_by_threads": {str(k): round(v, 4) for k, v in sorted(legs.items())},
@@ -594,7 +626,8 @@ def _map_stats(got, ref):
 def _worst(rows, vs, note):
     keys = ("raw_max_abs", "normalised_max_abs", "rel_linf")
     out = {k: max(r[k] for r in rows) for k in keys}
-    out.update({"samples": len(rows), "vs": vs, "note": note,
+    med = sorted(r["normalised_max_abs"] for r in rows)
+    out.update({"median_normalised_max_abs": med[len(med) // 2], "samples": len(rows), "vs": vs, "note": note,
                 "per_sample": [{"sample": r["sample"], **{k: float(f"{r[k]:.3e}") for k in keys}} for r in rows]})
     return out
 
@@ -621,16 +654,30 @@ def cpu_baseline_parity(args, wl, gpu_maps, ref_maps):
     B = wl.B
     got = gpu_maps.detach().float().cpu()
     self_rows = ref_maps.pop("self", []) if ref_maps else []
+    ref64 = ref_maps.pop("ref64", {}) if ref_maps else {}
     if ref_maps:
         rows = [{"sample": i, **_map_stats(got[i], m)} for i, m in sorted(ref_maps.items()) if i < B]
         out["vs_reference_cpu"] = _worst(rows, "reference CPU", "whole pipeline vs the reference's generate_LRP on the host "
                                          "cores (the cpu_baseline leg's own maps): different producers, see DESIGN.md section 4")
+        if ref64 and "error" not in ref64:
+            # the yardstick for vs_reference_cpu: the SAME reference code and weights evaluated in fp64 on the same inputs.
+            # LRP divides by mixed-sign sums near zero, so with random-init weights at start_layer 1 the reference's fp32 map
+            # is itself far from its fp64 map; "ours" is held against the same fp64 map beside it
+            r32 = [{"sample": i, **_map_stats(ref_maps[i], m)} for i, m in sorted(ref64.items()) if i in ref_maps]
+            o64 = [{"sample": i, **_map_stats(got[i], m)} for i, m in sorted(ref64.items()) if i < B]
+            out["reference_fp32_vs_reference_fp64"] = _worst(r32, "reference CPU fp64", "the reference's fp32 map against its "
+                                                             "own fp64 evaluation (same code, weights, inputs)")
+            out["ours_vs_reference_fp64"] = _worst(o64, "reference CPU fp64", "this pipeline's maps against the reference's "
+                                                   "fp64 evaluation of the same inputs")
+        elif ref64:
+            out["reference_fp64_error"] = ref64["error"]
         if self_rows:
             keys = ("raw_max_abs", "normalised_max_abs", "rel_linf")
             out["reference_cpu_vs_itself"] = {
                 **{k: max(r[k] for r in self_rows) for k in keys}, "samples": len(self_rows),
-                "note": "the reference's own maps of the same inputs under another torch thread count (another fp32 GEMM summation "
-                        "order on the same host): the floor under vs_reference_cpu for these random-init weights",
+                "note": "the reference's own maps of the same inputs under another torch thread count on the same host (oneDNN / "
+                        "MKL keep the k-order of a GEMM when they re-partition rows over threads, so this only shows the host "
+                        "path is deterministic; the yardstick for vs_reference_cpu is reference_fp32_vs_reference_fp64)",
                 "per_sample": [{"sample": r["sample"], "threads": r["threads"], **{k: float(f"{r[k]:.3e}") for k in keys}}
                                for r in self_rows]}
     is_vit = wl.name.startswith("vit")
