@@ -41,6 +41,32 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path, defin
     assert bad == 0, f"{bad} instruction(s) touch a register with a hidden load in flight (see the captured output)"
 
 
+@pytest.mark.parametrize("defines", [[], ["-DTE_STUDY"]], ids=["shipped", "study"])
+def test_rc_kernels_straight_line_hidden_loads(tmp_path, defines):
+    """csrc/te_attn_rc.hip (round 6: the QK rule / softmax backward with row-block and key-block owners) keeps its hidden loads
+    in STRAIGHT-LINE code -- its first, rolled version had hipcc copy loop-carried registers with loads in flight on the
+    back-edge, which this checker found before the kernel ever ran -- and is checked by one linear walk over each kernel:
+    448 / 504 hidden loads, no instruction may touch a destination before its hand-counted wait."""
+    build = _load("_te_build_isa_rc", os.path.join(ROOT, "transformer-explainability_amd", "build.py"))
+    checker = _load("_te_check_hidden_loads_rc", os.path.join(ROOT, "scripts", "check_hidden_loads.py"))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "te_attn_rc.s"
+    cmd = [hipcc, *build.CXXFLAGS, *defines, "--cuda-device-only", "-S", "-I", build.INCLUDE, "-I", build.CSRC,
+           os.path.join(build.CSRC, "te_attn_rc.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    lines = out.read_text().split("\n")
+    found = list(checker.kernels(lines, "qk_rc_kernel"))
+    assert len(found) == 2, "qk_rc_kernel<RULE> / <BWD> were not found in the ISA listing"
+    for name, lo, hi in found:
+        assert sum("buffer_load_dword" in ln for ln in lines[lo:hi]) >= 400
+        # the loop-based check reports on (and only on) loops that contain a hidden load: none may be left
+        assert checker.check(lines, lo, hi, name) == 0
+    bad = sum(checker.check_linear(lines, lo, hi, name) for name, lo, hi in found)
+    assert bad == 0, f"{bad} instruction(s) touch a register with a hidden load in flight (see the captured output)"
+
+
 def test_checker_sees_a_planted_copy(tmp_path):
     """The checker itself: a listing with a move of an in-flight register before its wait, and on the loop back-edge."""
     checker = _load("_te_check_hidden_loads2", os.path.join(ROOT, "scripts", "check_hidden_loads.py"))
@@ -61,3 +87,18 @@ def test_checker_sees_a_planted_copy(tmp_path):
     assert len(found) == 1
     name, lo, hi = found[0]
     assert checker.check(listing, lo, hi, name) == 2      # line 9 (in the body) and line 5 (second trip: carried over the back-edge)
+    # the linear walk (straight-line kernels) sees the copy in the body too, and a wait that is one step short
+    assert checker.check_linear(listing, lo, hi, name) >= 1
+    short = """_ZN4test9rc_kernelEv:
+\tbuffer_load_dword v4, v1, s[0:3], 0 offen
+\tbuffer_load_dword v5, v1, s[0:3], 0 offen
+\ts_waitcnt vmcnt(1)
+\tv_add_f32_e32 v9, v4, v4
+\tv_add_f32_e32 v9, v5, v5
+\ts_waitcnt vmcnt(0)
+\tv_add_f32_e32 v9, v5, v5
+\ts_endpgm
+.Lfunc_end0:
+""".split("\n")
+    (name, lo, hi), = list(checker.kernels(short, "rc_kernel"))
+    assert checker.check_linear(short, lo, hi, name) == 1  # v5 read under vmcnt(1): its load is the one still in flight

@@ -24,7 +24,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libte_relprop.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 
-SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_linear_x6.hip", "te_attn.hip", "te_attn_mfma.hip", "te_attn_rules.hip", "te_attn_kb.hip", "te_attn_long.hip", "te_norm_act.hip",
+SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_linear_x6.hip", "te_attn.hip", "te_attn_mfma.hip", "te_attn_rules.hip", "te_attn_kb.hip", "te_attn_rc.hip", "te_attn_long.hip", "te_norm_act.hip",
            "te_rollout.hip", "te_heatmap.hip", "te_conv.hip", "te_perturb.hip"]
 
 CXXFLAGS = [
@@ -71,21 +71,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, "te_common.h"), os.path.join(INCLUDE, "te_relprop.h"), __file__]
-    # measurement builds only (benchmarks/): TE_BUILD_DEFINES="TE_X6_STUDY" adds -D flags and forces a rebuild
+    # measurement builds only (benchmarks/, scripts/): TE_BUILD_DEFINES="TE_X6_STUDY" adds -D flags; they are built NEXT TO the
+    # shipped library (lib/libte_relprop_study.so, objects in build_study/) and selected with TE_RELPROP_LIB, so that a
+    # measurement never replaces the library the tests load
     extra = ["-D" + d for d in os.environ.get("TE_BUILD_DEFINES", "").split() if d]
-    force = force or bool(extra)
+    obj_dir, lib_path = (OBJ_DIR + "_study", LIB_PATH.replace(".so", "_study.so")) if extra else (OBJ_DIR, LIB_PATH)
+    os.makedirs(obj_dir, exist_ok=True)
     # provenance: a content hash of every source + the flags, baked into te_api.o (te_build_id()) and
     # checked by _lib.load() against the tree.  A changed id recompiles te_api.hip even when its own mtime says "fresh".
     bid = _buildid_module().build_id([*CXXFLAGS, *extra])
-    stamp = os.path.join(OBJ_DIR, "build_id.txt")
+    stamp = os.path.join(obj_dir, "build_id.txt")
     old_bid = open(stamp).read().strip() if os.path.exists(stamp) else None
-    if old_bid == bid and os.path.exists(LIB_PATH) and not force:
-        return LIB_PATH          # same sources, same flags: up to date whatever the mtimes of a copied tree say
+    if old_bid == bid and os.path.exists(lib_path) and not force:
+        return lib_path          # same sources, same flags: up to date whatever the mtimes of a copied tree say
     objs, rebuilt = [], False
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         stale_id = src == "te_api.hip" and old_bid != bid
         if force or stale_id or _newer(s, o) or any(_newer(h, o) for h in headers):
@@ -102,9 +105,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    if rebuilt or force or not os.path.exists(LIB_PATH):
+    if rebuilt or force or not os.path.exists(lib_path):
         tl = torch_lib_dir()
-        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path]
         if tl:
             link += ["-L", tl, "-Wl,-rpath," + tl]
         link += ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
@@ -115,7 +118,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("link failed:\n" + r.stdout)
     with open(stamp, "w") as f:
         f.write(bid + "\n")
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":

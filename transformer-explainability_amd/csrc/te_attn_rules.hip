@@ -59,6 +59,14 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
               float* qpart, const float* r_scale, int64_t r_scale_stride, int* ngroups_out, hipStream_t stream);
 }  // namespace te_attn_kb
 
+namespace te_attn_rc {      // te_attn_rc.hip: row-block and key-block owners (round 6) -- the default QK rule / softmax backward, N <= 224
+bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
+int qk_launch(int mode, const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
+              int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, float* cam_k,
+              int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale, const float* r_scale,
+              int64_t r_scale_stride, hipStream_t stream);
+}  // namespace te_attn_rc
+
 namespace te_attn_rules {
 
 namespace {
@@ -939,6 +947,21 @@ static bool use_kb_qk() {
 #endif
 }
 
+// which QK-rule / softmax-backward kernels run at N <= 224: 1 (default) = te_attn_rc.hip (row-block and key-block owners, bf16
+// MFMAs on split operands), 0 = qk_rule_kernel above (round 2).  TE_ATTN_QK=old selects the round-2 kernel in measurement
+// builds (-DTE_STUDY) for same-box A/B runs.
+static bool use_rc_qk() {
+#ifdef TE_STUDY
+  static const bool on = [] {
+    const char* e = getenv("TE_ATTN_QK");
+    return !(e && (!strcmp(e, "old") || !strcmp(e, "x6")));
+  }();
+  return on;
+#else
+  return true;
+#endif
+}
+
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   int ng, jg;
   groups_for(N, ng, jg);
@@ -972,6 +995,9 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   groups_for(N, ng, jg);
   const int BH = (int)(B * H);
   if (q_sn > 65536) return TE_ERR_UNSUPPORTED;                       // 32-bit row offsets inside a (b, h) view
+  if (use_rc_qk() && te_attn_rc::supported(B, H, N, 64))
+    return te_attn_rc::qk_launch(0, Rnn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn, cam_k, ck_sb, ck_sh,
+                                 ck_sn, B, H, N, scale, r_scale, r_scale_stride, stream);
   if (use_kb_qk() && te_attn_kb::supported(B, H, N, 64)) {
     const Strided qs{q_sb, q_sh, q_sn}, cqs{cq_sb, cq_sh, cq_sn};
     int kng = 1;
@@ -1046,7 +1072,13 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
                                                                         qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
                                                                         (int)H, (int)N, BH, jg, 1.0f, nullptr);
   }
-  if (need_qk) {
+  if (need_qk && use_rc_qk() && te_attn_rc::supported(B, H, N, 64)) {
+    // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q   (te_attn_rc.hip)
+    int rc = te_attn_rc::qk_launch(1, d_attn, qkv, fused.sb, fused.sh, fused.sn, qkv + C, fused.sb, fused.sh, fused.sn, attn, d_qkv,
+                                   fused.sb, fused.sh, fused.sn, d_qkv + C, fused.sb, fused.sh, fused.sn, B, H, N, scale, nullptr, 0,
+                                   stream);
+    if (rc != TE_OK) return rc;
+  } else if (need_qk) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q
     allow_lds(qk_rule_kernel<BWD>, lds_qk(256, true));
     qk_rule_kernel<BWD><<<dim3((unsigned)BH), dim3(kT), lds_qk(jg, true), stream>>>(d_attn, attn, qkv, fused, qkv + C, fused,
