@@ -962,6 +962,21 @@ static bool use_rc_qk() {
 #endif
 }
 
+// The softmax half of the backward pass on te_attn_rc.hip: measured against qk_rule_kernel<BWD> on one box (profiles/
+// r06_attention_qk_rc_ab.log) it wins below ~160 tokens (69 vs 75 us at N = 128), ties at 224 and LOSES at 197 (the headline:
+// 272 vs 257 us for the whole backward pair -- its separate rowdot pass over the row panels), so it serves N <= 160 only;
+// TE_ATTN_QK=rc_bwd forces it in measurement builds.
+static bool use_rc_bwd(int64_t N) {
+#ifdef TE_STUDY
+  static const int forced = [] {
+    const char* e = getenv("TE_ATTN_QK");
+    return (e && !strcmp(e, "rc_bwd")) ? 1 : (e && (!strcmp(e, "old") || !strcmp(e, "x6"))) ? -1 : 0;
+  }();
+  if (forced) return forced > 0;
+#endif
+  return N <= 160;
+}
+
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   int ng, jg;
   groups_for(N, ng, jg);
@@ -1072,7 +1087,7 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
                                                                         qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
                                                                         (int)H, (int)N, BH, jg, 1.0f, nullptr);
   }
-  if (need_qk && use_rc_qk() && te_attn_rc::supported(B, H, N, 64)) {
+  if (need_qk && use_rc_bwd(N) && te_attn_rc::supported(B, H, N, 64)) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q   (te_attn_rc.hip)
     int rc = te_attn_rc::qk_launch(1, d_attn, qkv, fused.sb, fused.sh, fused.sn, qkv + C, fused.sb, fused.sh, fused.sn, attn, d_qkv,
                                    fused.sb, fused.sh, fused.sn, d_qkv + C, fused.sb, fused.sh, fused.sn, B, H, N, scale, nullptr, 0,
