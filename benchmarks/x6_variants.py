@@ -38,6 +38,8 @@ VARIANTS = {
     "g64": 3,                             # every launch on 128 x 128 tiles (three workgroups per CU)
     "z64": 3 << ops.TE_X6_TILE_Z_SHIFT,
     "c64": 3 << ops.TE_X6_TILE_C_SHIFT,
+    # round 6, study builds only (TE_RELPROP_LIB=.../libte_relprop_study.so): schedule options of x6_kernel, set through TE_X6_OPT
+    # "opt<bits>" (any value): default flags, TE_X6_OPT=<bits> while the variant runs (kX6Opt*: 4 = no epilogue, 8 = warm-up requests)
 }
 
 
@@ -100,7 +102,11 @@ def main():
         ref = {}
         for it in range(a.iters + 2):
             for v in names:
-                fl = VARIANTS[v]
+                fl = 0 if v.startswith("opt") else VARIANTS[v]
+                if v.startswith("opt"):
+                    os.environ["TE_X6_OPT"] = v[3:]
+                else:
+                    os.environ.pop("TE_X6_OPT", None)
                 pairs = {}
                 rule(fl | ops.TE_X6_PHASE_SPLIT)
                 for key, fn in (("z", lambda: rule(fl | ops.TE_X6_PHASE_Z)), ("c", lambda: rule(fl | ops.TE_X6_PHASE_C)),
@@ -119,7 +125,8 @@ def main():
                     if not ref:
                         ref["r"] = cur
                     else:
-                        assert all(torch.equal(x, y) for x, y in zip(cur, ref["r"])), f"{v}: results differ from {names[0]}"
+                        garbage = v.startswith("opt") and int(v[3:]) & 0x74      # ablations of the epilogue: wrong by construction
+                        assert garbage or all(torch.equal(x, y) for x, y in zip(cur, ref["r"])), f"{v}: results differ from {names[0]}"
         torch.cuda.synchronize()
         ops.x6_raise_if_failed(dev)
         gemm = 2.0 * T * in_f * out_f

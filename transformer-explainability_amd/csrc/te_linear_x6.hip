@@ -401,7 +401,20 @@ struct X6Params {
   float scale;                 // MODE_C / MODE_CI / MODE_X: factor on the result (alpha, -beta)
   int accum;                   // MODE_X: 1 = add to what out holds (MODE_CI always does)
   int x_sign;                  // MODE_X: +1 = X+ masks the product, -1 = X-
+  int opt;                     // schedule options (kX6Opt*): results do not depend on them
 };
+// (round 6, measured and removed: requesting the NEXT tile's first stage before the epilogue, non-temporal epilogue accesses, and
+// warm-up requests of the tile's R / Y lines during the last loop steps -- all neutral or negative, profiles/r06_x6_epilogue_study.log)
+constexpr int kX6OptSkipEpilogue = 4;      // measurement builds: no epilogue (what it costs in place; garbage results)
+constexpr int kX6OptDefault = 0;
+
+// keeps a vector value alive without using it (study paths).  Device pass only: a "v" constraint in the HOST pass of a kernel
+// template silently drops the host stub of the instantiation (the ablation kernels 1-4 / 6 stopped linking that way).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define X6_KEEP(v) asm volatile("" ::"v"(v))
+#else
+#define X6_KEEP(v) (void)(v)
+#endif
 
 __device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -804,11 +817,21 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
         }                                         // accumulators are live here, a batch of all 32 loads would spill
     }
 
+#ifdef TE_X6_STUDY
+    if (p.opt & kX6OptSkipEpilogue) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) X6_KEEP(acc[mi][ni]);
+      __syncthreads();
+      continue;
+    }
+#endif
     if constexpr (!EPI) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+        for (int ni = 0; ni < 2; ++ni) X6_KEEP(acc[mi][ni]);
       __syncthreads();
       if constexpr (PROF) {
         if (threadIdx.x == 0) {
@@ -853,6 +876,13 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
         const int ni = bi / MI, mi = bi % MI;
         const int j0 = (tm * (NWM * MI) + wm * MI + mi) * 32;
         const float* Rrow = p.R + tl[ni] * p.out_f + j0 + 4 * h;
+#ifdef TE_X6_STUDY      // TE_X6_OPT bit 4: the epilogue without its R / Y loads (garbage results: what the loads cost)
+        if (p.opt & 16) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) r4[buf][g] = f32x4{1.0f, 2.0f, 3.0f, 4.0f}, y4[buf][g] = f32x4{1.0f, 2.0f, 3.0f, 4.0f};
+          return;
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) r4[buf][g] = *reinterpret_cast<const f32x4*>(Rrow + 8 * g);
         if constexpr (MODE != MODE_Z1) {
@@ -916,6 +946,15 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
           for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int d = 0; d < 2; ++d) swap_halves(w[g][q][d], w[g + 2][q][d]);
+#ifdef TE_X6_STUDY      // TE_X6_OPT bit 5: the epilogue without its S stores (garbage results: what the stores cost)
+        if (p.opt & 32) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(w[g][q][0]), "v"(w[g][q][1]));
+          continue;
+        }
+#endif
         if (blk[ni]) {
           unsigned char* Srow = p.S + (int64_t)cb * nksS * kRB + tc * 16;
           unsigned char* sp = Srow + (int64_t)((j0 >> 4) + h) * kRB;
@@ -1154,6 +1193,10 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
     q.whole_tiles = ((p.prefer_whole || std::ceil(r) <= kWholeTileSlack * r) && !p.small_grid) ? 1 : 0;
   if (!q.status) q.status = q.flags + kErrWord;
   q.spin_ticks = spin_ticks_for_current_device();
+  q.opt = kX6OptDefault;
+#ifdef TE_X6_STUDY      // measurement builds: TE_X6_OPT=<bits> overrides the schedule options, read per launch (benchmarks/x6_variants.py
+  if (const char* e_opt = getenv("TE_X6_OPT")) q.opt = atoi(e_opt);      // interleaves the variants in one process)
+#endif
   kern<<<dim3(8 * spx), dim3(GEO::THREADS), lds, stream>>>(q);
   return TE_OK;
 }
