@@ -405,15 +405,18 @@ struct X6Params {
 };
 // (round 6, measured and removed: requesting the NEXT tile's first stage before the epilogue, non-temporal epilogue accesses, and
 // warm-up requests of the tile's R / Y lines during the last loop steps -- all neutral or negative, profiles/r06_x6_epilogue_study.log)
+constexpr int kX6OptStaged = 8;            // Z modes, 128-row wave tiles: R / Y of the epilogue through the LDS, one cache line per load instruction
 constexpr int kX6OptSkipEpilogue = 4;      // measurement builds: no epilogue (what it costs in place; garbage results)
-constexpr int kX6OptDefault = 0;
+constexpr int kX6OptDefault = kX6OptStaged;
 
 // keeps a vector value alive without using it (study paths).  Device pass only: a "v" constraint in the HOST pass of a kernel
 // template silently drops the host stub of the instantiation (the ablation kernels 1-4 / 6 stopped linking that way).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define X6_KEEP(v) asm volatile("" ::"v"(v))
+#define X6_PASS4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))      // a no-op four loaded vectors pass through
 #else
 #define X6_KEEP(v) (void)(v)
+#define X6_PASS4(a, b, c, d) (void)0
 #endif
 
 __device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* lds_wave_base) {
@@ -453,6 +456,17 @@ struct X6Geo {
   static constexpr int MAX_SPX = (WM == 2) ? 32 : (WM == 1) ? 64 : 96;                   // workgroups per XCD
 };
 
+// LDS of a workgroup: the stages, or -- Z modes of the 128-row wave tiles -- the epilogue's staging area if that is larger (16 KiB per
+// wave: two buffers of one 32 x 32 block of R and of Y), then one 512-B bias slot per wave and the hand-over word
+template <int WM, int MODE, int NST>
+struct X6Lds {
+  using GEO = X6Geo<WM>;
+  static constexpr bool STAGED = (MODE == MODE_Z || MODE == MODE_ZI || MODE == MODE_Z1) && GEO::MI == 4;
+  static constexpr int STAGES = NST * (GEO::NPA + GEO::NPB) * kFrag;
+  static constexpr int MAIN = (STAGED && GEO::NW * 16384 > STAGES) ? GEO::NW * 16384 : STAGES;
+  static constexpr int TOTAL = MAIN + GEO::NW * 512 + 16;
+};
+
 // KSPLIT = 2: a separate instantiation, so that launches without the K split carry none of its code or registers (with the
 // split as a run-time branch the Z-pass epilogue spilled 277 VGPRs and every un-split launch ran 6-16 % slower, measured).
 template <int WM, int MODE, int STUDY = 0, int NST = 2, int KSPLIT = 1>
@@ -472,6 +486,8 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
   constexpr int GROUPS = NPA / G;                    // A groups per tile: 4 WM (Z) or 2 WM (C)
   constexpr bool FULL = (STUDY == 0 || STUDY >= 4);  // study builds: 5 = shipped + time stamps, 6 = no epilogue + stamps
   constexpr bool EPI = (STUDY == 0 || STUDY == 5), PROF = (STUDY == 5 || STUDY == 6);
+  // Z modes on 128-row wave tiles stage the R / Y blocks of the epilogue through the (then idle) LDS: 16 KiB per wave (X6Staged)
+  constexpr int LDS_MAIN = X6Lds<WM, MODE, NST>::MAIN;
   long long prof_loop = 0, prof_epi = 0, prof_pub = 0, prof_wait = 0, prof_t0 = 0, prof_t1 = 0, prof_steps = 0, prof_nepi = 0;
   const long long prof_start = PROF ? wall_clock64() : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -565,7 +581,7 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
     // Bounded, loud wait for a flag another workgroup raises (release) once its accumulators are in memory; uniform
     // result.  On expiry: the caller's sticky status word and this pass's error word are set, `false` comes back.
     auto wait_for = [&](unsigned* flag) -> bool {
-      unsigned* const ok_word = reinterpret_cast<unsigned*>(smem + NST * STAGE + NW * 512);
+      unsigned* const ok_word = reinterpret_cast<unsigned*>(smem + LDS_MAIN + NW * 512);
       if (threadIdx.x == 0) {
         unsigned spins = 0, ok = 1u;
         const long long t_begin = wall_clock64();
@@ -863,12 +879,155 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
       }
       // the wave's 128 bias values go through a private 512-B LDS slot: reading them back counts on lgkmcnt, so no wait
       // for a bias value drains the prefetched R / Y loads of the next block
-      float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 128;
+      float* const bias_lds = reinterpret_cast<float*>(smem + LDS_MAIN) + wave * 128;
       if (lane < MI * 8) {
         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
         if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (NWM * MI) + wm * MI) * 32 + lane * 4);
         *reinterpret_cast<f32x4*>(bias_lds + lane * 4) = bv;
       }
+      bool staged_done = false;
+      if constexpr (X6Lds<WM, MODE, NST>::STAGED) {
+#ifdef TE_X6_STUDY      // (measurement builds keep the round-3 epilogue of these geometries behind TE_X6_OPT for same-box A/B runs)
+        const bool staged = (p.opt & kX6OptStaged) != 0;
+#else
+        constexpr bool staged = true;
+#endif
+        if (staged) {
+          staged_done = true;
+          // Round 6 (profiles/r06_x6_epilogue_study.log (5)): a lane of the accumulator layout owns the 16-byte pieces g = 0..3 of ONE
+          // 128-byte line of its row, so the four load instructions of a block touched the same 32 lines back to back and the in-order L1
+          // stalled on the pending fills.  Here every line is requested by ONE instruction: a direct-to-LDS load covers 8 rows x 128 B
+          // (8 lanes per line), chunk order XOR-permuted by the row so that the read-back in the accumulator layout -- lane (tc, h),
+          // piece g = chunk 2g + h of row tc -- is bank-conflict free: [row][128 B] images, row r holds chunk c at slot c ^ ((r >> 1) & 7).
+          constexpr int NL = (MODE == MODE_Z1) ? 4 : 8;                 // direct-to-LDS loads per block
+          __builtin_amdgcn_s_barrier();                                 // every wave has read its last fragments: the stages are free
+          unsigned char* const stg = smem + wave * 16384;               // two buffers of (R block, Y block)
+          unsigned rda[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            rda[g] = (unsigned)(uintptr_t)stg + tc * 128 + (((2 * g + h) ^ ((tc >> 1) & 7)) << 4);
+          const unsigned bia = (unsigned)(uintptr_t)bias_lds + h * 16;
+          const int r8 = lane >> 3;
+          auto request = [&](int bi, int buf) __attribute__((always_inline)) {
+            const int ni = bi / MI, mi = bi % MI;
+            const int cb = tn * (GEO::TT / 32) + wn * 2 + ni;
+            const int j0 = (tm * (NWM * MI) + wm * MI + mi) * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = 8 * i + r8;
+              const int64_t t = min((int64_t)cb * 32 + row, p.T - 1);
+              const int64_t off = t * p.out_f + j0 + (((lane & 7) ^ ((row >> 1) & 7)) << 2);
+              glds16(reinterpret_cast<const unsigned char*>(p.R + off), stg + buf * 8192 + i * 1024);
+              if constexpr (MODE != MODE_Z1)
+                glds16(reinterpret_cast<const unsigned char*>(p.Y + off), stg + buf * 8192 + 4096 + i * 1024);
+            }
+          };
+          // Two blocks in flight: block bi + 2 is requested into block bi's buffer as soon as block bi sits in registers.  The wait for
+          // block bi is hand-counted: younger in the queue are the loads of block bi + 1 and the S stores of blocks bi - 2 and bi - 1
+          // (six each, if the wave's row blocks exist: `all_blk`; else only the loads are counted, which waits longer, never shorter).
+          const bool all_blk = blk[0] && blk[1];
+          request(0, 0);
+          request(1, 1);
+#pragma unroll
+          for (int bi = 0; bi < 2 * MI; ++bi) {
+            const int ni = bi / MI, mi = bi % MI, buf = bi & 1;
+            const int cb = tn * (GEO::TT / 32) + wn * 2 + ni;
+            const int j0 = (tm * (NWM * MI) + wm * MI + mi) * 32;
+            constexpr int kStore = 6;
+            const int yl = (bi + 1 < 2 * MI) ? NL : 0, ys = (bi >= 2 ? kStore : 0) + (bi >= 1 ? kStore : 0);
+            if (all_blk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(yl + ys) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(yl) : "memory");
+            f32x4 r4[4], y4[4], b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r4[g]) : "v"(rda[g]), "i"(buf * 8192));
+              if constexpr (MODE != MODE_Z1)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(y4[g]) : "v"(rda[g]), "i"(buf * 8192 + 4096));
+              asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b4[g]) : "v"(bia), "i"((mi * 32 + 8 * g) * 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (bi + 2 < 2 * MI) request(bi + 2, buf);
+            X6_PASS4(r4[0], r4[1], r4[2], r4[3]);
+            if constexpr (MODE != MODE_Z1) X6_PASS4(y4[0], y4[1], y4[2], y4[3]);
+            X6_PASS4(b4[0], b4[1], b4[2], b4[3]);
+            unsigned w[4][3][2];
+            unsigned bad = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float sv4[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float a_abs = acc[mi][ni][4 * g + c];
+                float z;
+                bool cancel;
+                if constexpr (MODE == MODE_Z) {
+                  z = 0.5f * ((y4[g][c] - b4[g][c]) + a_abs);
+                  cancel = !(z > kCancelTol * a_abs);
+                } else if constexpr (MODE == MODE_ZI) {
+                  z = 0.5f * ((y4[g][c] - b4[g][c]) - a_abs);
+                  cancel = !(-z > kCancelTol * a_abs);
+                } else {
+                  z = a_abs;
+                  cancel = false;
+                }
+                bad |= (cancel ? 1u : 0u) << (4 * g + c);
+                float rr = r4[g][c];
+                if (p.rs) rr = rr * f[ni];
+                float sv = te_sd(rr, z);
+                asm volatile("" : "+v"(sv));
+                sv4[c] = (live[ni] && !cancel) ? sv : 0.0f;
+              }
+              unsigned lo[3], hi[3];
+              split3_pk(sv4[0], sv4[1], lo);
+              split3_pk(sv4[2], sv4[3], hi);
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                w[g][q][0] = lo[q];
+                w[g][q][1] = hi[q];
+              }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+              for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) swap_halves(w[g][q][d], w[g + 2][q][d]);
+            if (blk[ni]) {
+              unsigned char* Srow = p.S + (int64_t)cb * nksS * kRB + tc * 16;
+              unsigned char* sp = Srow + (int64_t)((j0 >> 4) + h) * kRB;
+#pragma unroll
+              for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                  u32x4 v = {w[c][q][0], w[c][q][1], w[c + 2][q][0], w[c + 2][q][1]};
+                  *reinterpret_cast<u32x4*>(sp + q * kFrag + c * 512) = v;
+                }
+              if (!live[ni]) bad = 0;
+              if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const float* Rrow = p.R + tl[ni] * p.out_f;
+#pragma clang loop unroll(disable)
+                for (int e = 0; e < 16; ++e) {
+                  if ((bad >> e) & 1u) {
+                    const int jj = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
+                    const float z = (MODE == MODE_ZI) ? exact_zi(p.X + tl[ni] * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f)
+                                                      : exact_z(p.X + tl[ni] * p.in_f, p.W + (int64_t)jj * p.in_f, p.in_f);
+                    float rr = Rrow[jj];
+                    if (p.rs) rr = rr * f[ni];
+                    unsigned pl[3];
+                    split3(te_sd(rr, z), pl);
+                    unsigned short* d = reinterpret_cast<unsigned short*>(Srow + (int64_t)(jj >> 4) * kRB + ((jj >> 3) & 1) * 512) + (jj & 7);
+                    d[0] = (unsigned short)pl[0];
+                    d[kFrag / 2] = (unsigned short)pl[1];
+                    d[kFrag] = (unsigned short)pl[2];
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      if (!staged_done) {
       // (128 x 128 geometry: three waves per SIMD cover the load latency, and 168 VGPRs do not hold a second buffer)
       constexpr int NBUF = (MI == 4) ? 2 : 1;
       f32x4 r4[NBUF][4], y4[NBUF][4];
@@ -992,9 +1151,10 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
           }
         }
       }
+      }      // (!staged_done)
     } else if constexpr (MODE == MODE_G) {
       // plain product: out[t][m] = acc + bias[m] (fp32 row-major [T, M]); the wave's 128 bias values through its LDS slot
-      float* const bias_lds = reinterpret_cast<float*>(smem + NST * STAGE) + wave * 128;
+      float* const bias_lds = reinterpret_cast<float*>(smem + LDS_MAIN) + wave * 128;
       if (lane < MI * 8) {
         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
         if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + (tm * (NWM * MI) + wm * MI) * 32 + lane * 4);
@@ -1166,8 +1326,7 @@ inline long long spin_ticks_for_current_device() {
 template <int WM, int MODE, int STUDY = 0, int NST = 2, int KSPLIT = 1>
 int launch_x6(const X6Params& p, hipStream_t stream) {
   using GEO = X6Geo<WM>;
-  constexpr int NP = GEO::NPA + GEO::NPB;
-  constexpr int lds = NST * NP * kFrag + GEO::NW * 512 + 16;      // stages + one 512-B bias slot per wave + the hand-over word
+  constexpr int lds = X6Lds<WM, MODE, NST>::TOTAL;
   static_assert(lds * (WM == 0 ? 3 : WM == 1 ? 2 : 1) <= 160 * 1024, "LDS of the workgroups of one CU");
   static_assert((size_t)8 * GEO::MAX_SPX * GEO::THREADS * GEO::ACC * 4 <= kPartialBytes && 8 * GEO::MAX_SPX < kErrWord, "workspace");
   auto kern = x6_kernel<WM, MODE, STUDY, NST, KSPLIT>;
