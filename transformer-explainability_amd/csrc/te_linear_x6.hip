@@ -99,6 +99,25 @@ __device__ __forceinline__ void split3(float x, unsigned (&p)[3]) {
   for (int q = 0; q < 3; ++q) p[q] = pk[q] & 0xffffu;
 }
 
+// safe_divide (te_common.h: te_sd) of two element pairs on packed fp32 instructions, as in te_attn_rc.hip: den = b + 1e-9 (one
+// rounding), an exact-zero den replaced by 1e-9, a / den, zero where b == 0.  The quotient is the hardware's own expansion of an IEEE
+// division without its range scaling (v_rcp_f32, one Newton step on the reciprocal, q = a rc, the exact residual r = a - den q by
+// fma, q + r rc): correctly rounded wherever no intermediate leaves the normal range -- |den| >= 1e-16 by construction.
+__device__ __forceinline__ f32x2 sd2(f32x2 a, f32x2 b) {
+  f32x2 den = b + f32x2{1e-9f, 1e-9f};
+  den[0] = (den[0] == 0.0f) ? 1e-9f : den[0];
+  den[1] = (den[1] == 0.0f) ? 1e-9f : den[1];
+  f32x2 rc = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const f32x2 e = __builtin_elementwise_fma(-den, rc, f32x2{1.0f, 1.0f});
+  rc = __builtin_elementwise_fma(e, rc, rc);
+  f32x2 q = a * rc;
+  const f32x2 r = __builtin_elementwise_fma(-den, q, a);
+  q = __builtin_elementwise_fma(r, rc, q);
+  q[0] = (b[0] != 0.0f) ? q[0] : 0.0f;
+  q[1] = (b[1] != 0.0f) ? q[1] : 0.0f;
+  return q;
+}
+
 enum { OP_ABS = 0, OP_POS = 1, OP_NEG = 2, OP_ID = 3 };
 template <int OP>
 __device__ __forceinline__ float apply_op(float x) {
@@ -926,6 +945,21 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
           // block bi is hand-counted: younger in the queue are the loads of block bi + 1 and the S stores of blocks bi - 2 and bi - 1
           // (six each, if the wave's row blocks exist: `all_blk`; else only the loads are counted, which waits longer, never shorter).
           const bool all_blk = blk[0] && blk[1];
+#ifdef TE_X6_STUDY      // TE_X6_OPT bit 6: shader-clock stamps of the epilogue's phases, waves 0 and 4 (one SIMD) of workgroup 163
+          long long* const stamp_out = reinterpret_cast<long long*>(p.flags + 2048) + 4608 + (wave >> 2) * 64;
+          const bool stamping = (p.opt & 64) && bid == 163 && (wave & 3) == 0 && lane == 0;
+          int stamp_i = 0;
+#define X6_STAMP()                                                                              \
+  if (p.opt & 64) {                                                                             \
+    long long t_;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+    if (stamping) stamp_out[stamp_i] = t_;                                                      \
+    ++stamp_i;                                                                                  \
+  }
+#else
+#define X6_STAMP()
+#endif
+          X6_STAMP();
           request(0, 0);
           request(1, 1);
 #pragma unroll
@@ -935,8 +969,10 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
             const int j0 = (tm * (NWM * MI) + wm * MI + mi) * 32;
             constexpr int kStore = 6;
             const int yl = (bi + 1 < 2 * MI) ? NL : 0, ys = (bi >= 2 ? kStore : 0) + (bi >= 1 ? kStore : 0);
+            X6_STAMP();
             if (all_blk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(yl + ys) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(yl) : "memory");
+            X6_STAMP();
             f32x4 r4[4], y4[4], b4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -947,35 +983,45 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (bi + 2 < 2 * MI) request(bi + 2, buf);
+            X6_STAMP();
             X6_PASS4(r4[0], r4[1], r4[2], r4[3]);
             if constexpr (MODE != MODE_Z1) X6_PASS4(y4[0], y4[1], y4[2], y4[3]);
             X6_PASS4(b4[0], b4[1], b4[2], b4[3]);
+            // Element pairs on packed fp32 instructions (z, the division: sd2 -- an IEEE quotient without its range scaling, correctly
+            // rounded inside the normal range).  Which elements cancel is kept as wave-level lane masks (the compare's own result,
+            // OR-ed on the scalar unit); the per-lane bit mask the fallback wants is rebuilt only if one is set.
             unsigned w[4][3][2];
-            unsigned bad = 0;
+            unsigned long long any_cancel = 0;
+            auto z_of = [&](int g, int c0, f32x2& z2, f32x2& a2) __attribute__((always_inline)) {
+              a2 = f32x2{acc[mi][ni][4 * g + c0], acc[mi][ni][4 * g + c0 + 1]};
+              if constexpr (MODE == MODE_Z)            // Z  = X+ W+^T + X- W-^T = ((Y - b) + |X||W|^T) / 2  (>= 0)
+                z2 = f32x2{0.5f, 0.5f} * ((f32x2{y4[g][c0], y4[g][c0 + 1]} - f32x2{b4[g][c0], b4[g][c0 + 1]}) + a2);
+              else if constexpr (MODE == MODE_ZI)      // Z' = X+ W-^T + X- W+^T = ((Y - b) - |X||W|^T) / 2  (<= 0)
+                z2 = f32x2{0.5f, 0.5f} * ((f32x2{y4[g][c0], y4[g][c0 + 1]} - f32x2{b4[g][c0], b4[g][c0 + 1]}) - a2);
+              else                                     // one-sided product: the accumulator is Z
+                z2 = a2;
+            };
+            auto cancels = [&](float z, float a_abs) __attribute__((always_inline)) -> bool {
+              if constexpr (MODE == MODE_Z) return !(z > kCancelTol * a_abs);
+              else if constexpr (MODE == MODE_ZI) return !(-z > kCancelTol * a_abs);
+              else return false;
+            };
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               float sv4[4];
 #pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const float a_abs = acc[mi][ni][4 * g + c];
-                float z;
-                bool cancel;
-                if constexpr (MODE == MODE_Z) {
-                  z = 0.5f * ((y4[g][c] - b4[g][c]) + a_abs);
-                  cancel = !(z > kCancelTol * a_abs);
-                } else if constexpr (MODE == MODE_ZI) {
-                  z = 0.5f * ((y4[g][c] - b4[g][c]) - a_abs);
-                  cancel = !(-z > kCancelTol * a_abs);
-                } else {
-                  z = a_abs;
-                  cancel = false;
+              for (int c0 = 0; c0 < 4; c0 += 2) {
+                f32x2 z2, a2;
+                z_of(g, c0, z2, a2);
+                f32x2 rr = {r4[g][c0], r4[g][c0 + 1]};
+                if (p.rs) rr = rr * f32x2{f[ni], f[ni]};
+                const f32x2 sv = sd2(rr, z2);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  const bool cancel = cancels(z2[e], a2[e]);
+                  if constexpr (MODE != MODE_Z1) any_cancel |= __builtin_amdgcn_ballot_w64(cancel);
+                  sv4[c0 + e] = (live[ni] && !cancel) ? sv[e] : 0.0f;
                 }
-                bad |= (cancel ? 1u : 0u) << (4 * g + c);
-                float rr = r4[g][c];
-                if (p.rs) rr = rr * f[ni];
-                float sv = te_sd(rr, z);
-                asm volatile("" : "+v"(sv));
-                sv4[c] = (live[ni] && !cancel) ? sv : 0.0f;
               }
               unsigned lo[3], hi[3];
               split3_pk(sv4[0], sv4[1], lo);
@@ -986,12 +1032,33 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
                 w[g][q][1] = hi[q];
               }
             }
+            unsigned bad = 0;                          // elements whose Z needs the cancellation fallback
+            if (any_cancel != 0) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int c0 = 0; c0 < 4; c0 += 2) {
+                  f32x2 z2, a2;
+                  z_of(g, c0, z2, a2);
+                  bad |= (cancels(z2[0], a2[0]) ? 1u : 0u) << (4 * g + c0);
+                  bad |= (cancels(z2[1], a2[1]) ? 1u : 0u) << (4 * g + c0 + 1);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
               for (int q = 0; q < 3; ++q)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) swap_halves(w[g][q][d], w[g + 2][q][d]);
+#ifdef TE_X6_STUDY
+            if (p.opt & 64) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) asm volatile("" : "+v"(w[g][q][0]), "+v"(w[g][q][1]));      // (the arithmetic ends before the stamp)
+            }
+#endif
+            X6_STAMP();
             if (blk[ni]) {
               unsigned char* Srow = p.S + (int64_t)cb * nksS * kRB + tc * 16;
               unsigned char* sp = Srow + (int64_t)((j0 >> 4) + h) * kRB;
@@ -1024,7 +1091,9 @@ __global__ __launch_bounds__(X6Geo<WM>::THREADS, X6Geo<WM>::WPS) void x6_kernel(
                 }
               }
             }
+            X6_STAMP();
           }
+#undef X6_STAMP
         }
       }
       if (!staged_done) {
