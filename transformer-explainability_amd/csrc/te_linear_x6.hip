@@ -1407,7 +1407,13 @@ int launch_x6(const X6Params& p, hipStream_t stream) {
   q.ntm = p.rows_w / GEO::TM;
   q.ntn = (int)te_ceil_div(p.T, GEO::TT);
   const int64_t tiles = (int64_t)q.ntm * q.ntn * q.ksplit;      // work items
-  const int max_spx = p.small_grid ? 2 : GEO::MAX_SPX;
+  int max_spx = p.small_grid ? 2 : GEO::MAX_SPX;
+#ifdef TE_X6_STUDY      // TE_X6_CUS_PER_XCD=<n <= 32>: leave 32 - n CUs of every XCD to the kernels of other streams (overlapped-step study)
+  if (const char* e_cu = getenv("TE_X6_CUS_PER_XCD")) {
+    const int n = atoi(e_cu);
+    if (n >= 1 && n <= 32 && !p.small_grid) max_spx = GEO::MAX_SPX * n / 32;
+  }
+#endif
   const int spx = (int)std::min<int64_t>(max_spx, std::max<int64_t>(1, te_ceil_div(tiles, 8)));
   // Stream-K or whole tiles?  With equal (tile, k) ranges the workgroups of an XCD sit at different k offsets of their
   // tiles and nothing one of them fetches is still in the 4 MB L2 when its neighbour needs it; cut at tile boundaries
