@@ -67,6 +67,11 @@ int qk_launch(int mode, const float* Rnn, const float* q, int64_t q_sb, int64_t 
               int64_t r_scale_stride, hipStream_t stream);
 }  // namespace te_attn_rc
 
+namespace te_attn_fwd6 {      // te_attn_fwd6.hip: row-block owners on bf16 MFMAs (round 6) -- the default attention forward, N <= 224
+bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
+int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream);
+}  // namespace te_attn_fwd6
+
 namespace te_attn_rules {
 
 namespace {
@@ -1056,6 +1061,17 @@ extern "C" int te_attention_forward_f32(const float* qkv, float* z_qk, float* at
   if (!qkv || !z_qk || !attn || !out || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
   if (!te_attention_forward_supported(N, D) || B * H > 0x7fffffff) return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
+#ifdef TE_STUDY      // TE_ATTN_FWD=old selects the round-2 kernel in measurement builds for same-box A/B runs
+  static const bool old_fwd = [] { const char* e = getenv("TE_ATTN_FWD"); return e && !strcmp(e, "old"); }();
+#else
+  constexpr bool old_fwd = false;
+#endif
+  if (!old_fwd && te_attn_fwd6::supported(B, H, N, D)) {
+    const int rc = te_attn_fwd6::launch(qkv, z_qk, attn, out, B, H, N, scale, stream);
+    if (rc != TE_OK) return rc;
+    TE_RETURN_IF_LAUNCH_FAILED();
+    return TE_OK;
+  }
   te_attn_rules::allow_lds(te_attn_rules::attn_fwd_kernel, te_attn_rules::kLdsFwd);
   te_attn_rules::attn_fwd_kernel<<<dim3((unsigned)(B * H)), dim3(te_attn_rules::kT), te_attn_rules::kLdsFwd, stream>>>(
       qkv, z_qk, attn, out, (int)H, (int)N, scale);
