@@ -13,8 +13,8 @@
 //     staged once per workgroup), B = the wave's own 32 rows of q (planes in registers), so a lane (i, h) ends up with ITS query
 //     row's scores for the keys 32 jb + 8 g + 4 h + (0..3): runs of four consecutive keys = 16-byte pieces of z_qk and attn rows,
 //     and the row's softmax is a reduction over the lane's own 4 x 7 x 4 registers plus one exchange with lane i + 32;
-//   * out, transposed:     O[d][i] = sum_j v[j][d] p[i][j]  -- A = v^T (planes in LDS, staged over k's after one barrier, K order =
-//     the accumulator layout's: stage_vt), B = the probabilities straight from the accumulator registers, split into planes per
+//   * out, transposed:     O[d][i] = sum_j v[j][d] p[i][j]  -- A = v^T (planes in LDS, written over k's after one barrier from loads
+//     requested before the first product, K order = the accumulator layout's: request_vt / write_vt), B = the probabilities straight from the accumulator registers, split into planes per
 //     K16 step; a lane (i, h) ends up with out[i][32 mb + 8 g + 4 h + (0..3)]: 16-byte pieces of the 'b n (h d)' row;
 //   * both products on v_mfma_f32_32x32x16_bf16 with three-way split operands (te_linear_x6.hip: an fp32 value is the exact sum of
 //     three bf16 values; the six partial products above 2^-24, smallest first, fp32 accumulation): fp32-class accuracy
@@ -65,51 +65,67 @@ __device__ __forceinline__ void planes_of8(const float (&x)[8], bf16x8 (&b)[3]) 
 // k [rows < N][64] as A planes with M = key, K = d:  Pk[plane 3][step 4][jb NB][kh 2][r 32][8]: element = plane q of
 // k[32 jb + r][16 step + 8 kh + t].  One item = 8 consecutive d of one key: 8 threads cover the 256 bytes of a key's row.
 __device__ __forceinline__ void stage_k(unsigned char* __restrict__ Pk, const float* __restrict__ k, int64_t sn, int N, int NB) {
-  for (int item = threadIdx.x; item < NB * 32 * 8; item += kT) {
-    const int j = item >> 3, c8 = item & 7;               // key, (step, kh) = chunk of 8 d
-    const int step = c8 >> 1, kh = c8 & 1;
+  constexpr int kItems = (kMaxB * 32 * 8 + kT - 1) / kT;             // items per thread at most (4): every request first, then the splits
+  f32x4 v0[kItems], v1[kItems];
+#pragma unroll
+  for (int u = 0; u < kItems; ++u) {
+    const int item = threadIdx.x + u * kT, j = item >> 3, c8 = item & 7;
     const float* src = k + (int64_t)min(j, N - 1) * sn + 8 * c8;
-    const f32x4 v0 = *reinterpret_cast<const f32x4_u*>(src), v1 = *reinterpret_cast<const f32x4_u*>(src + 4);
-    float x[8];
+    v0[u] = *reinterpret_cast<const f32x4_u*>(src), v1[u] = *reinterpret_cast<const f32x4_u*>(src + 4);
+  }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = (j < N) ? v0[e] : 0.0f, x[4 + e] = (j < N) ? v1[e] : 0.0f;
-    bf16x8 b[3];
-    planes_of8(x, b);
-    unsigned char* dst = Pk + (size_t)(step * NB + (j >> 5)) * kFrag + (kh * 32 + (j & 31)) * 16;
+  for (int u = 0; u < kItems; ++u) {
+    const int item = threadIdx.x + u * kT;
+    if (item < NB * 32 * 8) {
+      const int j = item >> 3, c8 = item & 7;             // key, (step, kh) = chunk of 8 d
+      const int step = c8 >> 1, kh = c8 & 1;
+      float x[8];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(dst + (size_t)q * 4 * NB * kFrag) = b[q];
+      for (int e = 0; e < 4; ++e) x[e] = (j < N) ? v0[u][e] : 0.0f, x[4 + e] = (j < N) ? v1[u][e] : 0.0f;
+      bf16x8 b[3];
+      planes_of8(x, b);
+      unsigned char* dst = Pk + (size_t)(step * NB + (j >> 5)) * kFrag + (kh * 32 + (j & 31)) * 16;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(dst + (size_t)q * 4 * NB * kFrag) = b[q];
+    }
   }
 }
 
 // v [rows < N][64] as A planes with M = d, K = key, the K order of a B operand that came out of an MFMA accumulator (te_attn_rc.hip:
 // stage_planes<true>):  Pv[plane 3][step NS][mb 2][kh 2][r 32][8]: element t = plane q of v[16 step + 8 (t >> 2) + 4 kh + (t & 3)][32 mb + r].
 // One item = 8 keys x 4 consecutive d: eight 16-B loads (a half-wave covers 256 contiguous bytes of a row).  Keys >= N: 0.
-__device__ __forceinline__ void stage_vt(unsigned char* __restrict__ Pv, const float* __restrict__ v, int64_t sn, int N, int NS) {
-  for (int item = threadIdx.x; item < NS * 2 * 16; item += kT) {
-    const int c = item & 15, g8 = item >> 4;
-    const int step = g8 >> 1, kh = g8 & 1;
-    f32x4 x[8];
+// (request: at most one item per thread -- kMaxS * 2 * 16 = 448 <= 512 -- issued BEFORE the first product so that the loads fly beside it;
+//  write: after the barrier that frees the k planes)
+__device__ __forceinline__ void request_vt(f32x4 (&x)[8], const float* __restrict__ v, int64_t sn, int N, int NS) {
+  const int item = min((int)threadIdx.x, NS * 2 * 16 - 1);
+  const int c = item & 15, g8 = item >> 4;
+  const int step = g8 >> 1, kh = g8 & 1;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int row = 16 * step + 8 * (t >> 2) + 4 * kh + (t & 3);
-      x[t] = *reinterpret_cast<const f32x4_u*>(v + (int64_t)min(row, N - 1) * sn + 4 * c);
-    }
+  for (int t = 0; t < 8; ++t) {
+    const int row = 16 * step + 8 * (t >> 2) + 4 * kh + (t & 3);
+    x[t] = *reinterpret_cast<const f32x4_u*>(v + (int64_t)min(row, N - 1) * sn + 4 * c);
+  }
+}
+__device__ __forceinline__ void write_vt(unsigned char* __restrict__ Pv, f32x4 (&x)[8], int N, int NS) {
+  const int item = threadIdx.x;
+  if (item >= NS * 2 * 16) return;
+  const int c = item & 15, g8 = item >> 4;
+  const int step = g8 >> 1, kh = g8 & 1;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int row = 16 * step + 8 * (t >> 2) + 4 * kh + (t & 3);
+  for (int t = 0; t < 8; ++t) {
+    const int row = 16 * step + 8 * (t >> 2) + 4 * kh + (t & 3);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) x[t][e] = (row < N) ? x[t][e] : 0.0f;
-    }
+    for (int e = 0; e < 4; ++e) x[t][e] = (row < N) ? x[t][e] : 0.0f;
+  }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int d = 4 * c + e;
-      const float col[8] = {x[0][e], x[1][e], x[2][e], x[3][e], x[4][e], x[5][e], x[6][e], x[7][e]};
-      bf16x8 b[3];
-      planes_of8(col, b);
-      unsigned char* dst = Pv + (size_t)(step * 2 + (d >> 5)) * kFrag + (kh * 32 + (d & 31)) * 16;
+  for (int e = 0; e < 4; ++e) {
+    const int d = 4 * c + e;
+    const float col[8] = {x[0][e], x[1][e], x[2][e], x[3][e], x[4][e], x[5][e], x[6][e], x[7][e]};
+    bf16x8 b[3];
+    planes_of8(col, b);
+    unsigned char* dst = Pv + (size_t)(step * 2 + (d >> 5)) * kFrag + (kh * 32 + (d & 31)) * 16;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(dst + (size_t)q * NS * 2 * kFrag) = b[q];
-    }
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(dst + (size_t)q * NS * 2 * kFrag) = b[q];
   }
 }
 
@@ -199,6 +215,8 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
     }
   }
   __syncthreads();
+  f32x4 vreq[8];
+  request_vt(vreq, v_bh, sn, N, NS);
 
   float* const tile = reinterpret_cast<float*>(Pl + planes_bytes) + wave * (32 * kTileLd);      // wave-private [32][36] tile
   f32x16 acc[kMaxB];      // scores, then probabilities: acc[jb][4 g + c] <-> key 32 jb + 8 g + 4 h + c of row i
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
     }
   }
   __syncthreads();                                         // every wave is done with the k planes
-  stage_vt(Pl, v_bh, sn, N, NS);
+  write_vt(Pl, vreq, N, NS);
   __syncthreads();
   if (owner) {
     const unsigned char* const frag = Pl + lane * 16;
