@@ -130,6 +130,7 @@ def _e2e_vs_fp64(name, ours, prefix, k_median=2.0, k_median_l2=None, k_max=1.5):
     reference's own evaluations exceed 1.5 in one draw of ten (90th percentile 1.83 / 1.45), and round 6's attention
     forward -- closer to fp64 than the kernel it replaced on every output, scripts/attn_fwd_accuracy.py -- drew 1.18 / 1.66."""
     import numpy as np
+    from scipy.stats import binom
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_fp64.npz"))
     idx = [int(i) for i in fx[prefix + ".samples"]]
     ref32 = torch.from_numpy(fx[prefix + ".ref32"]).double()
@@ -161,11 +162,23 @@ def _e2e_vs_fp64(name, ours, prefix, k_median=2.0, k_median_l2=None, k_max=1.5):
                         "median_reference_pool_" + key: float(np.median(pool)), "worst_ours_" + key: float(ours_d.max()),
                         "worst_reference_pool_" + key: float(pool.max()), "reference_draws_per_sample": int(pool.shape[1]),
                         "ratio_median_" + key: float(np.median(ours_d) / np.median(pool)),
-                        "ratio_worst_" + key: float(ours_d.max() / pool.max())})
+                        "ratio_worst_" + key: float(ours_d.max() / pool.max()),
+                        # the tail, counted: our samples beyond the pool's 90th percentile, against the 99th percentile of a
+                        # Binomial(samples, 0.1) -- what the reference's own evaluations would show
+                        "pool_q90_" + key: float(np.quantile(pool, 0.9)),
+                        "beyond_pool_q90_" + key: int((ours_d > np.quantile(pool, 0.9)).sum()),
+                        "beyond_pool_q90_bound_" + key: int(binom.ppf(0.99, len(ours_d), 0.1))})
     record(name + ".e2e_vs_fp64", **summary, per_sample=rows)
     assert summary["ratio_median_norm_linf"] <= bound["norm_linf"], (name, summary)
     assert summary["ratio_median_rel_l2"] <= bound["rel_l2"], (name, summary)
-    assert summary["ratio_worst_norm_linf"] <= k_max and summary["ratio_worst_rel_l2"] <= k_max, (name, summary)
+    # worst case: the normalised map is a bounded quantity (what imagenet_seg_eval.py:217 thresholds) and is held against the
+    # reference pool's worst; the relative L2 of the raw map is unbounded and one near-cancelled element owns it (sample 24 of the
+    # headline fixture: three of the reference's own draws at 2e-4, the fourth at 0.28) -- its tail is COUNTED instead of compared
+    # with a maximum over 96 draws that a 97th would exceed (round 5 held ratio_worst_rel_l2 <= 1.5: 0.93 then, 3.0 with round 6's
+    # attention forward, two other samples 60x BETTER than before in the same run)
+    assert summary["ratio_worst_norm_linf"] <= k_max, (name, summary)
+    for key in ("norm_linf", "rel_l2"):
+        assert summary["beyond_pool_q90_" + key] <= summary["beyond_pool_q90_bound_" + key], (name, key, summary)
     return summary
 
 
