@@ -1013,7 +1013,7 @@ def main():
         try:   # HBM-side bytes per C-pass launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
                # MI355X guide's gfx950 correction); only valid for the workload they were collected on
             if args.config == "vit_b16_224" and B == 64:
-                cands = (("r05_linear_x6_traffic_pmc.json", "r04_linear_x6_traffic_pmc.json", "r03_linear_x6_traffic_pmc.json") if args.linear == "x6" else
+                cands = (("r06_linear_x6_traffic_pmc.json", "r05_linear_x6_traffic_pmc.json", "r04_linear_x6_traffic_pmc.json", "r03_linear_x6_traffic_pmc.json") if args.linear == "x6" else
                          ("r03_linear_traffic_pmc.json", "r02_linear_traffic_pmc.json", "r01_linear_traffic_pmc.json"))
                 for cand in cands:
                     path = os.path.join(ROOT, "profiles", cand)

@@ -1072,7 +1072,10 @@ int av_launch(int mode, const float* R, int64_t r_sb, int64_t r_sh, int64_t r_sn
   int ng, kbg;
   groups_for(N, ng, kbg);
   const int BH = (int)(B * H);
-  if (r_sn > 65536 || z_sn > 65536) return TE_ERR_UNSUPPORTED;      // 32-bit row offsets inside a (b, h) view
+  // 32-bit row offsets inside a (b, h) view, and the hardware range check that drops the rows >= N of a partial key block needs
+  // a row stride of at least the 64 floats a row holds: every strided view of the launch
+  auto stride_ok = [](int64_t sn) { return sn >= 64 && sn <= 65536; };
+  if (!stride_ok(r_sn) || !stride_ok(v_sn) || !stride_ok(cv_sn) || (mode == 0 && !stride_ok(z_sn))) return TE_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)(BH * ng)), blk(kT);
   const Strided rs{r_sb, r_sh, r_sn}, zs{z_sb, z_sh, z_sn}, vs{v_sb, v_sh, v_sn}, cs{cv_sb, cv_sh, cv_sn};
 #ifdef TE_STUDY
