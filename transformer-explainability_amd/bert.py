@@ -56,11 +56,14 @@ class _FusedSelfAttention(torch.autograd.Function):
         if xsc is None:
             xsc = zqk.new_empty(0)
         ctx.mark_non_differentiable(attn, zqk, xsc)
+        ctx.set_materialize_grads(False)      # no [B,H,N,N] zero gradients for the by-products (vit._FusedAttention)
         return out, attn, zqk, xsc
 
     @staticmethod
     def backward(ctx, d_out, _a, _z, _x):
         q, k, v, attn = ctx.saved_tensors
+        if d_out is None:
+            return None, None, None, None, None, None, None
         stop = bool(getattr(ctx.module, "_fused_stop_backward", False))
         d_v = torch.empty_like(v)
         d_q = None if stop else torch.empty_like(q)
