@@ -10,9 +10,10 @@ here ``relprop`` calls one fused closed-form kernel through the C ABI (include/t
 Batch semantics: the reference is batch-1 only; a batch of B samples is B independent batch-1
 problems (Add's "whole tensor" sums are per sample).  With B = 1 the results match the reference.
 
-Off the accelerated hot path ("API surface"): Conv2d / BatchNorm2d / pools /
-Cat / AddEye / Mul keep their forward so models build and run, but their relprop (used only by
-method="full") raises NotImplementedError here.
+Off the accelerated hot path ("API surface"): BatchNorm2d / pools / Cat / AddEye /
+Mul keep their forward so models build and run, but their relprop raises NotImplementedError here.
+Conv2d.relprop (method="full": the patch embedding's z^B rule, layers_ours.py:256-286) is implemented
+(csrc/te_conv.hip).
 """
 from __future__ import annotations
 
