@@ -20,14 +20,14 @@ import csv, glob, collections, re
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(av6?_kb_kernel<\d|qk6?_kb_kernel<\d|fwd_rows_kernel|av_rule_kernel<\d|qk_rule_kernel<\d|attn_fwd_kernel|qk_finish_kernel)", r["Kernel_Name"])
+        m = re.search(r"(av6?_kb_kernel<\d|qk6?_kb_kernel<\d|fwd_rows_kernel|av_rule_kernel<\d|qk_rule_kernel<\d|qk_rc_kernel<\d|fwd6_kernel|attn_fwd_kernel|qk_finish_kernel)", r["Kernel_Name"])
         if m:
             k = m.group(1).replace("av6_", "av_").replace("qk6_", "qk_")
             rows[k + (">" if "<" in k else "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 B, H, N = 64, 12, 197      # scripts/attn_bench.py's shape; <0> = relprop rule, <1> = the backward producer on the same kernel
 nn, nc = 2 * H * N * N, N * H * 64
 alg = {"av_kb_kernel<0>": (nn + 5 * nc) * 4 * B, "av_kb_kernel<1>": (nn + 4 * nc) * 4 * B, "qk_kb_kernel<0>": (nn + 4 * nc) * 4 * B, "qk_kb_kernel<1>": (nn + 4 * nc) * 4 * B, "fwd_rows_kernel": (nn + 4 * nc) * 4 * B, "av_rule_kernel<0>": (nn + 5 * nc) * 4 * B, "qk_rule_kernel<0>": (nn + 4 * nc) * 4 * B,
-       "attn_fwd_kernel": (nn + 4 * nc) * 4 * B, "av_rule_kernel<1>": (nn + 4 * nc) * 4 * B,
+       "attn_fwd_kernel": (nn + 4 * nc) * 4 * B, "fwd6_kernel": (nn + 4 * nc) * 4 * B, "qk_rc_kernel<0>": (nn + 4 * nc) * 4 * B, "qk_rc_kernel<1>": (nn + 4 * nc) * 4 * B, "av_rule_kernel<1>": (nn + 4 * nc) * 4 * B,
        "qk_rule_kernel<1>": (nn + 4 * nc) * 4 * B}
 out = ["kernel,counter,mean_per_dispatch,dispatches"]
 for k, cs in sorted(rows.items()):
