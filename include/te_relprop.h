@@ -397,6 +397,13 @@ int te_attention_forward_f32(const float* qkv, float* z_qk, float* attn, float* 
                              int64_t B, int64_t H, int64_t N, int64_t D, float scale, te_stream_t stream);
 int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn, float* d_qkv,
                               int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk, te_stream_t stream);
+/* The same with the block's forward output `out` [B,N,H*D] (what te_attention_forward_f32 wrote) at hand (round 6): the row
+ * sums of the softmax backward are then taken as sum_d d_out[i][d] out[i][d] (= sum_j attn[i][j] d_attn[i][j]: out = attn v,
+ * d_attn = d_out v^T) instead of from a pass over the two N x N tensors.  Results agree with te_attention_backward_f32 to
+ * fp32 rounding (another summation of the same quantity), not bit for bit. */
+int te_attention_backward_out_f32(const float* d_out, const float* out, const float* qkv, const float* attn, float* d_attn,
+                                  float* d_qkv, int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk,
+                                  te_stream_t stream);
 
 /* The same producers for the shapes the one-workgroup-per-head kernels cannot hold (csrc/te_attn_long.hip): head dim 64,
  * N <= 640 (ViT-L/16 at 384^2: 577, baselines/ViT/ViT_LRP.py:419-425; BERT: 512), q / k / v / out / gradients as

@@ -79,6 +79,24 @@ def test_attention_backward_producer(B, H, N, need_qk):
     if need_qk:
         check(f"producer.bwd.d_q({B},{H},{N})", d_qkv[..., :C], qkv.grad[..., :C], 1e-5)
         check(f"producer.bwd.d_k({B},{H},{N})", d_qkv[..., C:2 * C], qkv.grad[..., C:2 * C], 1e-5)
+        # round 6: with the forward output at hand the row sums of the softmax backward come from d_out . out
+        # (te_attention_backward_out_f32; N <= 224: the rc kernel for every such N) -- same bars, same d_attn / d_v bits,
+        # and a batch equals its samples bit for bit
+        out_k, attn_k2, _ = ops.attention_forward(qkv.detach(), H, scale)
+        d_attn2, d_qkv2 = ops.attention_backward(g_out, qkv.detach(), attn_k2, H, scale, need_qk=True, out=out_k)
+        assert torch.equal(d_attn2, d_attn) and torch.equal(d_qkv2[..., 2 * C:], d_qkv[..., 2 * C:])
+        # The bar: 1e-5 of the gradient's maximum or -- where the softmax backward cancels, d_s = attn (d_attn - rowsum) ~ 0, at
+        # N = 1 exactly 0 -- of the magnitude of the terms that cancel (scale |d_attn| |k|): the row sum is the same quantity
+        # summed another way, so what is left of a cancellation is rounding of that size, not of the result's.
+        nat = float(scale * attn.grad.abs().max() * qkv.detach().abs().max())
+        for nm, sl in (("d_q", slice(0, C)), ("d_k", slice(C, 2 * C))):
+            err = float((d_qkv2[..., sl] - qkv.grad[..., sl]).abs().max())
+            bar = 1e-5 * max(float(qkv.grad[..., sl].abs().max()), nat)
+            record(f"producer.bwd_out.{nm}({B},{H},{N})", max_abs=err, bar=bar)
+            assert torch.isfinite(d_qkv2[..., sl]).all() and err <= bar, (nm, B, H, N, err, bar)
+        one = ops.attention_backward(g_out[:1].contiguous(), qkv.detach()[:1].contiguous(), attn_k2[:1].contiguous(), H, scale,
+                                     need_qk=True, out=out_k[:1].contiguous())
+        assert torch.equal(one[1], d_qkv2[:1])
     # (need_qk=False: the q / k thirds of d_qkv are scratch -- the block has no consumer for them)
 
 

@@ -495,7 +495,8 @@ __global__ __launch_bounds__(kT) void qk_rc_kernel(const float* __restrict__ Rnn
                                                    const float* __restrict__ q, Strided qs, const float* __restrict__ k,
                                                    Strided ks, float* __restrict__ cam_q, Strided cqs,
                                                    float* __restrict__ cam_k, Strided cks, int H, int N, float scale,
-                                                   const float* __restrict__ r_scale, int64_t r_scale_stride, int both) {
+                                                   const float* __restrict__ r_scale, int64_t r_scale_stride, int both,
+                                                   const float* __restrict__ dO, const float* __restrict__ O, Strided os) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NS = (N + 15) >> 4, NB = (N + 31) >> 5;
   const size_t plane = (size_t)NS * 2 * kFrag;                         // one plane of one operand
@@ -520,7 +521,31 @@ __global__ __launch_bounds__(kT) void qk_rc_kernel(const float* __restrict__ Rnn
   RC_MARK(1);
   float rd_own = 0.0f;
   if constexpr (MODE == BWD) {
-    if (owner) {
+    if (dO != nullptr) {
+      // The row dots without a pass over the N x N tensors (round 6):  sum_j attn[i][j] d_attn[i][j] = sum_j attn[i][j] sum_d d_out[i][d]
+      // v[j][d] = sum_d d_out[i][d] out[i][d]  -- 64 products per row from the block's own forward output.  Four lanes per row,
+      // sixteen products each in ascending d, the partials meet in a fixed butterfly: an order that depends on nothing.
+      const float* dO_bh = dO + (int64_t)b * os.sb + (int64_t)h * os.sh;
+      const float* O_bh = O + (int64_t)b * os.sb + (int64_t)h * os.sh;
+      for (int r0 = 0; r0 < 32 * NB; r0 += kT / 4) {
+        const int i = r0 + (threadIdx.x >> 2), c = threadIdx.x & 3;
+        float part = 0.0f;
+        if (i < N) {
+          const float* a = dO_bh + (int64_t)i * os.sn + 16 * c;
+          const float* o = O_bh + (int64_t)i * os.sn + 16 * c;
+          f32x4 av[4], ov[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) av[u] = *reinterpret_cast<const f32x4_u*>(a + 4 * u), ov[u] = *reinterpret_cast<const f32x4_u*>(o + 4 * u);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part = part + av[u][e] * ov[u][e];
+        }
+        part = part + __shfl_xor(part, 1, 64);
+        part = part + __shfl_xor(part, 2, 64);
+        if (c == 0 && i < 32 * NB) rdv[i] = part;
+      }
+    } else if (owner) {
       row_dots(rdv, r_rs, z_rs, N, NB, wave);                          // (both phases read rows < 32 NB only)
     }
   }
@@ -620,10 +645,13 @@ bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
 
 // mode 0: the QK rule (Rnn = relevance of the scores, Z = the cached unscaled q k^T); mode 1: softmax backward (Rnn = d_attn,
 // Z = attn; cam_q / cam_k receive d_q / d_k).  Views [B,H,N,64] with element strides; Rnn, Z contiguous [B*H,N,N].
+// d_out / out (mode 1, optional): the attention block's output gradient and forward output as [B,H,N,64] views with the strides
+// o_s*: the row dots of the softmax backward then come from them instead of a pass over d_attn and attn.
 int qk_launch(int mode, const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
               int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, float* cam_k,
               int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale, const float* r_scale,
-              int64_t r_scale_stride, hipStream_t stream) {
+              int64_t r_scale_stride, hipStream_t stream, const float* d_out, const float* out, int64_t o_sb, int64_t o_sh,
+              int64_t o_sn) {
   if (!supported(B, H, N, 64)) return TE_ERR_UNSUPPORTED;
   const Strided qs{q_sb, q_sh, q_sn}, ks{k_sb, k_sh, k_sn}, cqs{cq_sb, cq_sh, cq_sn}, cks{ck_sb, ck_sh, ck_sn};
   const int both = lds_bytes(N, true) <= kLdsMax ? 1 : 0;
@@ -632,11 +660,13 @@ int qk_launch(int mode, const float* Rnn, const float* q, int64_t q_sb, int64_t 
   if (mode == RULE) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qk_rc_kernel<RULE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
     qk_rc_kernel<RULE><<<grid, dim3(kT), lds, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k, cks, (int)H, (int)N, scale, r_scale,
-                                                       r_scale_stride, both);
+                                                       r_scale_stride, both, nullptr, nullptr, Strided{0, 0, 0});
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(qk_rc_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    const bool from_out = d_out != nullptr && out != nullptr;
     qk_rc_kernel<BWD><<<grid, dim3(kT), lds, stream>>>(Rnn, Z, q, qs, k, ks, cam_q, cqs, cam_k, cks, (int)H, (int)N, scale, nullptr, 0,
-                                                      both);
+                                                      both, from_out ? d_out : nullptr, from_out ? out : nullptr,
+                                                      Strided{o_sb, o_sh, o_sn});
   }
   return TE_OK;
 }

@@ -64,7 +64,8 @@ bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
 int qk_launch(int mode, const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
               int64_t k_sh, int64_t k_sn, const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, float* cam_k,
               int64_t ck_sb, int64_t ck_sh, int64_t ck_sn, int64_t B, int64_t H, int64_t N, float scale, const float* r_scale,
-              int64_t r_scale_stride, hipStream_t stream);
+              int64_t r_scale_stride, hipStream_t stream, const float* d_out = nullptr, const float* out = nullptr, int64_t o_sb = 0,
+              int64_t o_sh = 0, int64_t o_sn = 0);
 }  // namespace te_attn_rc
 
 namespace te_attn_fwd6 {      // te_attn_fwd6.hip: row-block owners on bf16 MFMAs (round 6) -- the default attention forward, N <= 224
@@ -982,6 +983,16 @@ static bool use_rc_bwd(int64_t N) {
   return N <= 160;
 }
 
+// With the forward output at hand (te_attention_backward_out_f32) the rc kernel's row dots cost nothing and it serves every N <= 224;
+// TE_ATTN_QK=old keeps the round-2 kernel in measurement builds.
+static bool use_rc_bwd_out(bool have_out) {
+#ifdef TE_STUDY
+  static const bool old_only = [] { const char* e = getenv("TE_ATTN_QK"); return e && !strcmp(e, "old"); }();
+  if (old_only) return false;
+#endif
+  return have_out;
+}
+
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   int ng, jg;
   groups_for(N, ng, jg);
@@ -1079,9 +1090,11 @@ extern "C" int te_attention_forward_f32(const float* qkv, float* z_qk, float* at
   return TE_OK;
 }
 
-extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn,
-                                         float* d_qkv, int64_t B, int64_t H, int64_t N, int64_t D, float scale,
-                                         int need_qk, te_stream_t stream_) {
+// `out` (optional): the block's forward output [B,N,C].  With it the softmax half runs on te_attn_rc.hip for every N <= 224 -- its row
+// dots sum_j attn d_attn = sum_d d_out out need no pass over the N x N tensors then (te_attention_backward_out_f32).
+static int attention_backward_impl(const float* d_out, const float* out, const float* qkv, const float* attn, float* d_attn,
+                                   float* d_qkv, int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk,
+                                   te_stream_t stream_) {
   if (!d_out || !qkv || !attn || !d_attn || !d_qkv || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
   if (!te_attention_forward_supported(N, D) || B * H > 0x7fffffff) return TE_ERR_UNSUPPORTED;
   using namespace te_attn_rules;
@@ -1103,11 +1116,11 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
                                                                         qkv + 2 * C, fused, d_attn, d_qkv + 2 * C, fused,
                                                                         (int)H, (int)N, BH, jg, 1.0f, nullptr);
   }
-  if (need_qk && use_rc_bwd(N) && te_attn_rc::supported(B, H, N, 64)) {
+  if (need_qk && (use_rc_bwd(N) || use_rc_bwd_out(out != nullptr)) && te_attn_rc::supported(B, H, N, 64)) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q   (te_attn_rc.hip)
     int rc = te_attn_rc::qk_launch(1, d_attn, qkv, fused.sb, fused.sh, fused.sn, qkv + C, fused.sb, fused.sh, fused.sn, attn, d_qkv,
                                    fused.sb, fused.sh, fused.sn, d_qkv + C, fused.sb, fused.sh, fused.sn, B, H, N, scale, nullptr, 0,
-                                   stream);
+                                   stream, out ? d_out : nullptr, out, heads.sb, heads.sh, heads.sn);
     if (rc != TE_OK) return rc;
   } else if (need_qk) {
     // d_s = softmax backward * scale ; d_q = d_s k ; d_k = d_s^T q
@@ -1119,4 +1132,17 @@ extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, c
   }
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
+}
+
+extern "C" int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn,
+                                         float* d_qkv, int64_t B, int64_t H, int64_t N, int64_t D, float scale,
+                                         int need_qk, te_stream_t stream_) {
+  return attention_backward_impl(d_out, nullptr, qkv, attn, d_attn, d_qkv, B, H, N, D, scale, need_qk, stream_);
+}
+
+extern "C" int te_attention_backward_out_f32(const float* d_out, const float* out, const float* qkv, const float* attn,
+                                             float* d_attn, float* d_qkv, int64_t B, int64_t H, int64_t N, int64_t D,
+                                             float scale, int need_qk, te_stream_t stream_) {
+  if (!out) return TE_ERR_INVALID_ARG;
+  return attention_backward_impl(d_out, out, qkv, attn, d_attn, d_qkv, B, H, N, D, scale, need_qk, stream_);
 }

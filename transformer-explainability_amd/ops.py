@@ -712,9 +712,11 @@ def attention_forward(qkv: Tensor, num_heads: int, scale: float) -> Tuple[Tensor
 
 
 def attention_backward(d_out: Tensor, qkv: Tensor, attn: Tensor, num_heads: int, scale: float,
-                       need_qk: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+                       need_qk: bool = True, out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Gradient of attention_forward: d_out [B,N,C] -> (d_attn [B,H,N,N], d_qkv [B,N,3C]).  need_qk=False: nothing below
-    consumes d_qkv (the lowest block whose attention gradient is wanted): only d_attn is meaningful, d_qkv is scratch."""
+    consumes d_qkv (the lowest block whose attention gradient is wanted): only d_attn is meaningful, d_qkv is scratch.
+    out: the forward output attention_forward returned for these inputs, if the caller still holds it -- the softmax half then
+    takes its row sums from d_out . out (te_attention_backward_out_f32)."""
     d_out, qkv, attn = _c(d_out), _c(qkv), _c(attn)
     B, N, C3 = qkv.shape
     C = C3 // 3
@@ -728,9 +730,14 @@ def attention_backward(d_out: Tensor, qkv: Tensor, attn: Tensor, num_heads: int,
     d_attn = torch.empty_like(attn)
     with _on_device(qkv) as lib, _timed("attention_backward", (8.0 if need_qk else 4.0) * B * H * N * N * D,
                                         4.0 * B * ((4 if need_qk else 2) * H * N * N + 8 * N * C)):
-        _lib.check(lib.te_attention_backward_f32(_ptr(d_out), _ptr(qkv), _ptr(attn), _ptr(d_attn), _ptr(d_qkv), B, H, N,
-                                                 D, float(scale), int(bool(need_qk)), _stream(qkv)),
-                   "te_attention_backward_f32")
+        if out is not None and need_qk and tuple(out.shape) == tuple(d_out.shape) and out.is_contiguous() and out.dtype == d_out.dtype:
+            _lib.check(lib.te_attention_backward_out_f32(_ptr(d_out), _ptr(out), _ptr(qkv), _ptr(attn), _ptr(d_attn), _ptr(d_qkv),
+                                                         B, H, N, D, float(scale), 1, _stream(qkv)),
+                       "te_attention_backward_out_f32")
+        else:
+            _lib.check(lib.te_attention_backward_f32(_ptr(d_out), _ptr(qkv), _ptr(attn), _ptr(d_attn), _ptr(d_qkv), B, H, N,
+                                                     D, float(scale), int(bool(need_qk)), _stream(qkv)),
+                       "te_attention_backward_f32")
     return d_attn, d_qkv
 
 

@@ -79,7 +79,7 @@ class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, num_heads, scale, module):
         out, attn, zqk = ops.attention_forward(qkv, num_heads, scale)
-        ctx.save_for_backward(qkv, attn)
+        ctx.save_for_backward(qkv, attn, out)      # (out: the projection's input, alive anyway; the backward's row sums come from it)
         ctx.num_heads, ctx.scale, ctx.module = num_heads, scale, module
         ctx.mark_non_differentiable(attn, zqk)
         # (round 6) no zero gradients for the two by-products: autograd otherwise fills a [B,H,N,N] zero tensor for each of them
@@ -89,11 +89,11 @@ class _FusedAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, _d_attn_unused, _d_zqk_unused):
-        qkv, attn = ctx.saved_tensors
+        qkv, attn, out = ctx.saved_tensors
         if d_out is None:          # (nothing downstream of `out` reached the loss: with unmaterialised gradients that is a None)
             return None, None, None, None
         stop = bool(getattr(ctx.module, "_fused_stop_backward", False))
-        d_attn, d_qkv = ops.attention_backward(d_out, qkv, attn, ctx.num_heads, ctx.scale, need_qk=not stop)
+        d_attn, d_qkv = ops.attention_backward(d_out, qkv, attn, ctx.num_heads, ctx.scale, need_qk=not stop, out=out)
         ctx.module.save_attn_gradients(d_attn)
         return (None if stop else d_qkv), None, None, None
 
