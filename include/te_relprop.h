@@ -395,6 +395,13 @@ int te_gelu_forward_x6_planes_f32(const float* x, float* y, int64_t rows, int64_
 int te_attention_forward_supported(int64_t N, int64_t D);
 int te_attention_forward_f32(const float* qkv, float* z_qk, float* attn, float* out,
                              int64_t B, int64_t H, int64_t N, int64_t D, float scale, te_stream_t stream);
+/* te_attention_forward_f32 that also writes the operand planes of `out` for the projection layer's x6 kernels (round 6): out_planes =
+ * the signed planes of out [B N, H D], out_abs_planes (optional) = the planes of |out|, each te_linear_x6_planes_bytes(B N, H D)
+ * bytes, bit for bit what te_linear_x6_split_dual_f32 writes from the fp32 tensor (te_gemm_x6_f32's x_planes / the rule's
+ * x_abs_planes).  N <= 224. */
+int te_attention_forward_planes_f32(const float* qkv, float* z_qk, float* attn, float* out, void* out_planes,
+                                    void* out_abs_planes, size_t planes_bytes, int64_t B, int64_t H, int64_t N, int64_t D,
+                                    float scale, te_stream_t stream);
 int te_attention_backward_f32(const float* d_out, const float* qkv, const float* attn, float* d_attn, float* d_qkv,
                               int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk, te_stream_t stream);
 /* The same with the block's forward output `out` [B,N,H*D] (what te_attention_forward_f32 wrote) at hand (round 6): the row

@@ -541,3 +541,62 @@ def test_residual_layernorm_node(fused):
     assert torch.equal(x1, x)
     check("producer.residual_ln.fwd", n, nb.detach(), 3e-6)
     check("producer.residual_ln.bwd", dxa, dxb, 5e-6)
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 12, 197), (3, 2, 50), (1, 4, 224), (5, 2, 33), (2, 1, 1)])
+def test_attention_forward_emits_the_projection_planes(B, H, N):
+    """Round 6: te_attention_forward_planes_f32 = te_attention_forward_f32's bits plus the two plane sets
+    te_linear_x6_split_dual_f32 builds from `out` -- bit for bit, ragged last row block (B N not a multiple of 32) included."""
+    from transformer_explainability_amd import _lib, ops
+    d = dev()
+    lib = _lib.load()
+    D = 64
+    qkv = (rnd((B, N, 3 * H * D), 101) * 2.0).to(d)
+    scale = D ** -0.5
+    out0, attn0, z0 = ops.attention_forward(qkv, H, scale)
+    assert ops.attention_forward_planes_supported(qkv, H)
+    out1, attn1, z1, xs, xa = ops.attention_forward(qkv, H, scale, planes=True)
+    T, K = B * N, H * D
+    nb = lib.te_linear_x6_planes_bytes(T, K)
+    ref = [torch.zeros(nb, dtype=torch.uint8, device=d) for _ in range(2)]
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.te_linear_x6_split_dual_f32(out0.data_ptr(), T, K, ref[0].data_ptr(), ref[1].data_ptr(), nb, s), "dual")
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out0) and torch.equal(attn1, attn0) and torch.equal(z1, z0)
+    assert torch.equal(xs[:nb], ref[0]) and torch.equal(xa[:nb], ref[1])
+
+
+def test_attention_block_hands_planes_to_the_projection():
+    """vit.Attention on the producer kernels with the projection on the x6 kernels: the forward producer leaves proj's operand
+    planes in the layer's cache, the layer's split pass does not run, and output, attention gradient and the relprop result
+    are bitwise those of the separate passes (ops.X6_KEEP_ABS = False turns the hand-over off)."""
+    from transformer_explainability_amd import ops, rules, vit
+    d = dev()
+    torch.manual_seed(5)
+    res = {}
+    x = rnd((4, 197, 768), 111).to(d)
+    R = rnd((4, 197, 768), 112, 1e-3).to(d)
+    saved = (ops.USE_FUSED_PRODUCERS, ops.X6_GEMM, ops.USE_LINEAR_X6, ops.X6_KEEP_ABS)
+    try:
+        ops.USE_FUSED_PRODUCERS, ops.X6_GEMM, ops.USE_LINEAR_X6 = True, "all", True
+        blk = vit.Attention(768, num_heads=12, qkv_bias=True).to(d).eval()
+        for handover in (True, False):
+            ops.X6_KEEP_ABS = handover
+            calls = {"planes": 0}
+            orig = ops.attention_forward
+
+            def counting(*a, **k):
+                calls["planes"] += int(bool(k.get("planes")))
+                return orig(*a, **k)
+
+            ops.attention_forward = counting
+            try:
+                y = blk(x)
+            finally:
+                ops.attention_forward = orig
+            assert calls["planes"] == (1 if handover else 0)
+            cam = blk.proj.relprop(R, alpha=1)
+            res[handover] = (y.detach().clone(), cam.detach().clone())
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    finally:
+        ops.USE_FUSED_PRODUCERS, ops.X6_GEMM, ops.USE_LINEAR_X6, ops.X6_KEEP_ABS = saved

@@ -53,6 +53,7 @@ SIGNATURES = {
                                            _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_attention_forward_supported": (_I, [_I64, _I64]),
     "te_attention_forward_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _P]),
+    "te_attention_forward_planes_f32": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _I64, _I64, _I64, _I64, _F, _P]),
     "te_attention_backward_f32": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "te_attention_backward_out_f32": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _I, _P]),
     "te_attention_strided_supported": (_I, [_I64, _I64]),

@@ -178,8 +178,21 @@ __device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16
 
 constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};      // planes (1,1) (0,2) (2,0) (0,1) (1,0) (0,0): smallest first
 
+// (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second; te_linear_x6.hip)
+__device__ __forceinline__ void swap_halves(unsigned& lo_keep, unsigned& hi_keep) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(lo_keep, hi_keep, false, false);
+  lo_keep = r[0];
+  hi_keep = r[1];
+}
+
+// PLANES: `out` also leaves as the operand planes of the projection that consumes it -- the signed planes of out [B N, C] and the
+// planes of |out| in te_linear_x6.hip's fragment-major order P3[row / 32][k / 16][plane][kh][r 32][8 bf16], exactly what that layer's
+// split pass (te_linear_x6_split_dual_f32) would write from the fp32 tensor: the pass and its re-read of `out` disappear.
+template <bool PLANES>
 __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv, float* __restrict__ zqk, float* __restrict__ attn,
-                                                  float* __restrict__ out, int H, int N, float scale) {
+                                                  float* __restrict__ out, int H, int N, float scale,
+                                                  unsigned char* __restrict__ xs, unsigned char* __restrict__ xa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char Pl[];
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int C = H * 64;
@@ -332,7 +345,59 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<f32x4*>(o_row + 32 * mb + 8 * g) = f32x4{o[mb][4 * g], o[mb][4 * g + 1], o[mb][4 * g + 2], o[mb][4 * g + 3]};
     }
+    if constexpr (PLANES) {
+      // lane (i, h) holds out[i][32 mb + 8 g + 4 h + (0..3)]: K16 step 4 head + 2 mb + g / 2, k-half g % 2, positions 4 h .. 4 h + 3 of the
+      // eight.  The halves are exchanged as in the x6 Z epilogue: lanes h = 0 end up with the 16-byte pieces g = 0, 1, lanes h = 1
+      // with g = 2, 3.  |x| planes = x planes with plane 0's sign cleared and the low planes' signs flipped where x < 0 (split_kernel).
+      const int64_t t = (int64_t)b * N + i;
+      const int64_t nks = C >> 4;
+      unsigned char* const dst0 = (unsigned char*)nullptr + ((t >> 5) * nks * 3) * kFrag + (t & 31) * 16;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        unsigned w[4][3][2], wa[4][3][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          unsigned lo[3], hi[3];
+          split3_pk(o[mb][4 * g], o[mb][4 * g + 1], lo);
+          split3_pk(o[mb][4 * g + 2], o[mb][4 * g + 3], hi);
+          const unsigned m0 = lo[0] & 0x80008000u, m1 = hi[0] & 0x80008000u;
+          // (a zero residual is +0 whatever the sign of x: only non-zero halves of the low planes change sign -- split_kernel)
+          auto flip = [](unsigned p, unsigned m) { return p ^ (m & (((p & 0x7fff7fffu) + 0x7fff7fffu) & 0x80008000u)); };
+#pragma unroll
+          for (int q = 0; q < 3; ++q) w[g][q][0] = lo[q], w[g][q][1] = hi[q];
+          wa[g][0][0] = lo[0] & 0x7fff7fffu, wa[g][0][1] = hi[0] & 0x7fff7fffu;
+#pragma unroll
+          for (int q = 1; q < 3; ++q) wa[g][q][0] = flip(lo[q], m0), wa[g][q][1] = flip(hi[q], m1);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              swap_halves(w[g][q][d], w[g + 2][q][d]);
+              swap_halves(wa[g][q][d], wa[g + 2][q][d]);
+            }
+        if (row_ok) {
+          const size_t off = (size_t)(dst0 - (unsigned char*)nullptr) + (size_t)(4 * h + 2 * mb + kh) * 3 * kFrag;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              *reinterpret_cast<u32x4*>(xs + off + q * kFrag + c * 512) = u32x4{w[c][q][0], w[c][q][1], w[c + 2][q][0], w[c + 2][q][1]};
+              if (xa)
+                *reinterpret_cast<u32x4*>(xa + off + q * kFrag + c * 512) = u32x4{wa[c][q][0], wa[c][q][1], wa[c + 2][q][0], wa[c + 2][q][1]};
+            }
+        }
+      }
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned char* __restrict__ a, unsigned char* __restrict__ b) {
+  const size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  *reinterpret_cast<u32x4*>(a + off) = u32x4{0u, 0u, 0u, 0u};
+  if (b) *reinterpret_cast<u32x4*>(b + off) = u32x4{0u, 0u, 0u, 0u};
 }
 
 }  // namespace
@@ -341,13 +406,23 @@ bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
   return D == 64 && N >= 1 && N <= kMaxN && B >= 1 && H >= 1 && B * H <= 0x7fffffff;
 }
 
-int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream) {
+int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream,
+           void* out_planes, void* out_abs_planes) {
   const int NB = (int)((N + 31) >> 5), NS = (int)((N + 15) >> 4);
   // k planes, then v^T planes (<= 84 KB) + one [32][36] fp32 tile per wave
   const size_t lds = (size_t)3 * kFrag * (size_t)((4 * NB > 2 * NS) ? 4 * NB : 2 * NS) + (size_t)(kT / 64) * 32 * kTileLd * 4;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (out_planes && (B * N) % 32 != 0) {
+    // rows beyond B N of the last 32-row block: zero, as the split pass leaves them (a kernel, not a memset node: the producers are
+    // captured in HIP graphs, where memset nodes ran out of order on this stack -- DESIGN.md section 7)
+    const size_t tail = (size_t)H * 64 * 6 * 32, total = (size_t)((B * N + 31) / 32) * tail;      // (one 32-row block of planes)
+    zero_bytes_kernel<<<dim3((unsigned)(tail / 16 / 256)), dim3(256), 0, stream>>>((unsigned char*)out_planes + total - tail,
+                                                                                   out_abs_planes ? (unsigned char*)out_abs_planes + total - tail : nullptr);
+  }
+  auto kern = out_planes ? fwd6_kernel<true> : fwd6_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  fwd6_kernel<<<dim3((unsigned)(B * H)), dim3(kT), lds, stream>>>(qkv, z_qk, attn, out, (int)H, (int)N, scale);
+  kern<<<dim3((unsigned)(B * H)), dim3(kT), lds, stream>>>(qkv, z_qk, attn, out, (int)H, (int)N, scale, (unsigned char*)out_planes,
+                                                          (unsigned char*)out_abs_planes);
   return TE_OK;
 }
 

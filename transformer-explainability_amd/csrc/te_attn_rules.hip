@@ -70,7 +70,8 @@ int qk_launch(int mode, const float* Rnn, const float* q, int64_t q_sb, int64_t 
 
 namespace te_attn_fwd6 {      // te_attn_fwd6.hip: row-block owners on bf16 MFMAs (round 6) -- the default attention forward, N <= 224
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
-int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream);
+int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream,
+           void* out_planes = nullptr, void* out_abs_planes = nullptr);
 }  // namespace te_attn_fwd6
 
 namespace te_attn_rules {
@@ -1130,6 +1131,24 @@ static int attention_backward_impl(const float* d_out, const float* out, const f
                                                                            (int)H, (int)N, BH, jg, 1, scale, nullptr, nullptr,
                                                                            0);
   }
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
+// The forward producer that also writes the operand planes of `out` for the projection layer's x6 kernels (round 6):
+// out_planes = the signed planes of out [B N, H D] (te_linear_x6_planes_bytes(B N, H D) bytes each), out_abs_planes (optional) = the
+// planes of |out| -- bit for bit what te_linear_x6_split_dual_f32 writes from the fp32 tensor.  N <= 224 only (te_attn_fwd6.hip).
+extern "C" int te_attention_forward_planes_f32(const float* qkv, float* z_qk, float* attn, float* out, void* out_planes,
+                                               void* out_abs_planes, size_t planes_bytes, int64_t B, int64_t H, int64_t N,
+                                               int64_t D, float scale, te_stream_t stream_) {
+  if (!qkv || !z_qk || !attn || !out || !out_planes || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
+  if (!te_attention_forward_supported(N, D) || !te_attn_fwd6::supported(B, H, N, D)) return TE_ERR_UNSUPPORTED;
+  const size_t need = te_linear_x6_planes_bytes(B * N, H * D);
+  if (need == 0) return TE_ERR_UNSUPPORTED;
+  if (planes_bytes < need || !te_aligned16(out_planes) || (out_abs_planes && !te_aligned16(out_abs_planes))) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = te_attn_fwd6::launch(qkv, z_qk, attn, out, B, H, N, scale, stream, out_planes, out_abs_planes);
+  if (rc != TE_OK) return rc;
   TE_RETURN_IF_LAUNCH_FAILED();
   return TE_OK;
 }

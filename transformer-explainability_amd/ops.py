@@ -692,20 +692,40 @@ def attention_backward_qkv(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, attn:
     return d_attn
 
 
-def attention_forward(qkv: Tensor, num_heads: int, scale: float) -> Tuple[Tensor, Tensor, Tensor]:
+def attention_forward_planes_supported(qkv: Tensor, num_heads: int) -> bool:
+    """Can attention_forward emit the operand planes of its output (te_attention_forward_planes_f32: N <= 224, head dim 64)?"""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    return (qkv.is_cuda and qkv.dtype == torch.float32 and C % num_heads == 0 and C // num_heads == 64 and N <= 224
+            and bool(_lib.load().te_attention_forward_supported(N, 64)))
+
+
+def attention_forward(qkv: Tensor, num_heads: int, scale: float, planes: bool = False):
     """qkv [B,N,3C] ('b n (qkv h d)') -> (out [B,N,C] = softmax(q k^T * scale) v as 'b n (h d)', attn [B,H,N,N],
-    z_qk [B,H,N,N] = the unscaled q k^T).  ViT_LRP.py:132-152 without the q/k/v, scale, softmax and transpose passes."""
+    z_qk [B,H,N,N] = the unscaled q k^T).  ViT_LRP.py:132-152 without the q/k/v, scale, softmax and transpose passes.
+    planes=True (attention_forward_planes_supported): additionally the signed planes of out [B N, C] and the planes of |out| --
+    what gemm_x6's split pass over out would build -- as a fourth and fifth result."""
     qkv = _c(qkv)
     B, N, C3 = qkv.shape
     C = C3 // 3
     H, D = num_heads, C // num_heads
     if not _lib.load().te_attention_forward_supported(N, D):
+        if planes:
+            raise _lib.TeError("attention_forward(planes=True): shape not served by te_attention_forward_planes_f32")
         out, attn, zqk, _ = attention_forward_qkv(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], num_heads, scale)
         return out, attn, zqk
     out = torch.empty((B, N, C), dtype=torch.float32, device=qkv.device)
     attn = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
     zqk = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
-    with _on_device(qkv) as lib, _timed("attention_forward", 4.0 * B * H * N * N * D, 4.0 * B * (2 * H * N * N + 4 * N * C)):
+    extra = 12.0 * B * N * C if planes else 0.0
+    with _on_device(qkv) as lib, _timed("attention_forward", 4.0 * B * H * N * N * D, 4.0 * B * (2 * H * N * N + 4 * N * C) + extra):
+        if planes:
+            nb = lib.te_linear_x6_planes_bytes(B * N, C)
+            xs, xa = _ws(nb, qkv), _ws(nb, qkv)
+            _lib.check(lib.te_attention_forward_planes_f32(_ptr(qkv), _ptr(zqk), _ptr(attn), _ptr(out), _ptr(xs), _ptr(xa), nb,
+                                                           B, H, N, D, float(scale), _stream(qkv)),
+                       "te_attention_forward_planes_f32")
+            return out, attn, zqk, xs, xa
         _lib.check(lib.te_attention_forward_f32(_ptr(qkv), _ptr(zqk), _ptr(attn), _ptr(out), B, H, N, D, float(scale),
                                                 _stream(qkv)), "te_attention_forward_f32")
     return out, attn, zqk

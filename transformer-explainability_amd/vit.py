@@ -77,8 +77,15 @@ class _FusedAttention(torch.autograd.Function):
               wanted: nothing consumes d_qkv there, so only d_attn is formed."""
 
     @staticmethod
-    def forward(ctx, qkv, num_heads, scale, module):
-        out, attn, zqk = ops.attention_forward(qkv, num_heads, scale)
+    def forward(ctx, qkv, num_heads, scale, module, feeds=None):
+        # feeds (round 6): the cache dict of the projection layer, if that layer will run its forward product and its rule on
+        # the x6 kernels -- the producer then writes the operand planes of `out` itself and the layer's split pass disappears
+        # (the GELU pattern: producers._Gelu; the consumer checks that the planes belong to the tensor it receives)
+        if feeds is not None:
+            out, attn, zqk, xs, xa = ops.attention_forward(qkv, num_heads, scale, planes=True)
+            feeds["x_planes_from_producer"] = (ops._x_abs_key(out, out.numel() // out.shape[-1], out.shape[-1]), xs, xa, out)
+        else:
+            out, attn, zqk = ops.attention_forward(qkv, num_heads, scale)
         ctx.save_for_backward(qkv, attn, out)      # (out: the projection's input, alive anyway; the backward's row sums come from it)
         ctx.num_heads, ctx.scale, ctx.module = num_heads, scale, module
         ctx.mark_non_differentiable(attn, zqk)
@@ -91,11 +98,11 @@ class _FusedAttention(torch.autograd.Function):
     def backward(ctx, d_out, _d_attn_unused, _d_zqk_unused):
         qkv, attn, out = ctx.saved_tensors
         if d_out is None:          # (nothing downstream of `out` reached the loss: with unmaterialised gradients that is a None)
-            return None, None, None, None
+            return None, None, None, None, None
         stop = bool(getattr(ctx.module, "_fused_stop_backward", False))
         d_attn, d_qkv = ops.attention_backward(d_out, qkv, attn, ctx.num_heads, ctx.scale, need_qk=not stop, out=out)
         ctx.module.save_attn_gradients(d_attn)
-        return (None if stop else d_qkv), None, None, None
+        return (None if stop else d_qkv), None, None, None, None
 
 
 # the checkpoints the reference's factories fetch (ViT_LRP.py:24-36, 428-435 -- the same URLs in ViT_new.py / ViT_orig_LRP.py)
@@ -212,7 +219,16 @@ def make_vit_module(L):
             B, N, C = x.shape
             H, D = self.num_heads, C // self.num_heads
             qkv = self.qkv(x)
-            out, attn, zqk = _FusedAttention.apply(qkv, H, self.scale, self)
+            feeds = None
+            if isinstance(self.proj, L.Linear) and ops.attention_forward_planes_supported(qkv, H):
+                from .rules import x6_cache
+                out_f, in_f = self.proj.weight.shape
+                # (the layer's own plan for an input of out's shape: producers.linear_plan / producers.gelu)
+                if (in_f == C and ops.USE_FUSED_PRODUCERS and ops.X6_GEMM != "off" and not self.proj.training
+                        and ops.gemm_x6_wanted(B * N, in_f, out_f) and ops.USE_LINEAR_X6 and ops.X6_KEEP_ABS
+                        and ops.linear_relprop_x6_supported(B * N, in_f, out_f)):
+                    feeds = x6_cache(self.proj)
+            out, attn, zqk = _FusedAttention.apply(qkv, H, self.scale, self, feeds)
             self._fused_anchor = qkv if qkv.requires_grad else None
             q, k, v = qkv.detach().view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
             self.save_v(v)
