@@ -189,7 +189,10 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_keep, unsigned& hi_keep
 // PLANES: `out` also leaves as the operand planes of the projection that consumes it -- the signed planes of out [B N, C] and the
 // planes of |out| in te_linear_x6.hip's fragment-major order P3[row / 32][k / 16][plane][kh][r 32][8 bf16], exactly what that layer's
 // split pass (te_linear_x6_split_dual_f32) would write from the fp32 tensor: the pass and its re-read of `out` disappear.
-template <bool PLANES>
+// NB (row / key blocks of 32) is a template parameter: the whole pipeline of a wave is then ONE basic block and hipcc interleaves the
+// stores and exponentials of one key block with the MFMAs of the next (with run-time guards around every block the kernel was a chain of
+// 350 small blocks); the second product runs 2 NB K16 steps (keys beyond N: zero probabilities against zero planes).
+template <int NB, bool PLANES>
 __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv, float* __restrict__ zqk, float* __restrict__ attn,
                                                   float* __restrict__ out, int H, int N, float scale,
                                                   unsigned char* __restrict__ xs, unsigned char* __restrict__ xa) {
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int C = H * 64;
   const int64_t sn = 3 * (int64_t)C;
-  const int NB = (N + 31) >> 5, NS = (N + 15) >> 4;
-  const size_t planes_bytes = (size_t)3 * kFrag * (size_t)((4 * NB > 2 * NS) ? 4 * NB : 2 * NS);
+  constexpr int NS = 2 * NB;
+  constexpr size_t planes_bytes = (size_t)3 * kFrag * 4 * NB;      // k planes; the v^T planes take the same space
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31, kh = lane >> 5;
   const float* q_bh = qkv + (int64_t)b * N * sn + h * 64;
   const float* k_bh = q_bh + C;
@@ -232,40 +235,37 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
   request_vt(vreq, v_bh, sn, N, NS);
 
   float* const tile = reinterpret_cast<float*>(Pl + planes_bytes) + wave * (32 * kTileLd);      // wave-private [32][36] tile
-  f32x16 acc[kMaxB];      // scores, then probabilities: acc[jb][4 g + c] <-> key 32 jb + 8 g + 4 h + c of row i
+  f32x16 acc[NB];         // scores, then probabilities: acc[jb][4 g + c] <-> key 32 jb + 8 g + 4 h + c of row i
   if (owner) {
     const unsigned char* const frag = Pl + lane * 16;
-    const size_t plane_k = (size_t)4 * NB * kFrag;
+    constexpr size_t plane_k = (size_t)4 * NB * kFrag;
 #pragma unroll
-    for (int jb = 0; jb < kMaxB; ++jb)
+    for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[jb][e] = 0.0f;
     // four key blocks at a time: the same partial product of four independent accumulators between dependent MFMAs
 #pragma unroll
-    for (int jg = 0; jg < kMaxB; jg += 4) {
-      if (jg < NB) {
+    for (int jg = 0; jg < NB; jg += 4) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bf16x8 a[4][3];
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 a[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (jg + u < NB) a[u][q] = *reinterpret_cast<const bf16x8*>(frag + q * plane_k + (size_t)(s * NB + jg + u) * kFrag);
+#pragma unroll
+        for (int p6 = 0; p6 < 6; ++p6)
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)      // (blocks at or beyond NB re-read block NB - 1: finite values into accumulators nobody uses)
-              if (jg + u < kMaxB)
-                a[u][q] = *reinterpret_cast<const bf16x8*>(frag + q * plane_k + (size_t)(s * NB + min(jg + u, NB - 1)) * kFrag);
-#pragma unroll
-          for (int p6 = 0; p6 < 6; ++p6)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (jg + u < kMaxB) acc[jg + u] = TE_MFMA_BF16(a[u][PA[p6]], qb[s][PB[p6]], acc[jg + u]);
-        }
+            if (jg + u < NB) acc[jg + u] = TE_MFMA_BF16(a[u][PA[p6]], qb[s][PB[p6]], acc[jg + u]);
       }
     }
     // ---- z_qk leaves, the row's softmax in registers ('dots = einsum(...) * self.scale', ViT_LRP.py:139-141) ----
     float mx = -INFINITY;
 #pragma unroll
-    for (int jb = 0; jb < kMaxB; ++jb) {
-      if (jb < NB) {
+    for (int jb = 0; jb < NB; ++jb) {
+      {
         block_out(tile, acc[jb], z_bh, wave * 32, 32 * jb, N);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.0f;
 #pragma unroll
-    for (int jb = 0; jb < kMaxB; ++jb) {
-      if (jb < NB) {
+    for (int jb = 0; jb < NB; ++jb) {
+      {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           acc[jb][e] = exp_le0(acc[jb][e] - mx);           // exp(-inf) = 0 for the keys beyond N
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
     float rcs = __builtin_amdgcn_rcpf(sum);
     rcs = fmaf(fmaf(-sum, rcs, 1.0f), rcs, rcs);
 #pragma unroll
-    for (int jb = 0; jb < kMaxB; ++jb) {
-      if (jb < NB) {
+    for (int jb = 0; jb < NB; ++jb) {
+      {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x2 p0 = div2(f32x2{acc[jb][4 * g], acc[jb][4 * g + 1]}, sum, rcs);
@@ -312,15 +312,15 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
   __syncthreads();
   if (owner) {
     const unsigned char* const frag = Pl + lane * 16;
-    const size_t plane_v = (size_t)NS * 2 * kFrag;
+    constexpr size_t plane_v = (size_t)NS * 2 * kFrag;
     f32x16 o[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[mb][e] = 0.0f;
 #pragma unroll
-    for (int s = 0; s < kMaxS; ++s) {
-      if (s < NS) {
+    for (int s = 0; s < NS; ++s) {
+      {
         // K16 step s = keys 16 s .. 16 s + 15 = (jb = s / 2, g = 2 (s & 1), 2 (s & 1) + 1): B element t = 4 gg + c of lane (i, h)
         const int jb = s >> 1, g0 = 2 * (s & 1);
         const float x[8] = {acc[jb][4 * g0],     acc[jb][4 * g0 + 1], acc[jb][4 * g0 + 2], acc[jb][4 * g0 + 3],
@@ -408,9 +408,9 @@ bool supported(int64_t B, int64_t H, int64_t N, int64_t D) {
 
 int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream,
            void* out_planes, void* out_abs_planes) {
-  const int NB = (int)((N + 31) >> 5), NS = (int)((N + 15) >> 4);
-  // k planes, then v^T planes (<= 84 KB) + one [32][36] fp32 tile per wave
-  const size_t lds = (size_t)3 * kFrag * (size_t)((4 * NB > 2 * NS) ? 4 * NB : 2 * NS) + (size_t)(kT / 64) * 32 * kTileLd * 4;
+  const int NB = (int)((N + 31) >> 5);
+  // k planes, then v^T planes (12 KB per block of 32 keys: <= 84 KB) + one [32][36] fp32 tile per wave
+  const size_t lds = (size_t)3 * kFrag * 4 * NB + (size_t)(kT / 64) * 32 * kTileLd * 4;
   if (out_planes && (B * N) % 32 != 0) {
     // rows beyond B N of the last 32-row block: zero, as the split pass leaves them (a kernel, not a memset node: the producers are
     // captured in HIP graphs, where memset nodes ran out of order on this stack -- DESIGN.md section 7)
@@ -418,7 +418,15 @@ int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, in
     zero_bytes_kernel<<<dim3((unsigned)(tail / 16 / 256)), dim3(256), 0, stream>>>((unsigned char*)out_planes + total - tail,
                                                                                    out_abs_planes ? (unsigned char*)out_abs_planes + total - tail : nullptr);
   }
-  auto kern = out_planes ? fwd6_kernel<true> : fwd6_kernel<false>;
+  void (*kern)(const float*, float*, float*, float*, int, int, float, unsigned char*, unsigned char*) = nullptr;
+  switch (NB * 2 + (out_planes ? 1 : 0)) {
+#define TE_FWD6_CASE(nb) \
+    case nb * 2: kern = fwd6_kernel<nb, false>; break; \
+    case nb * 2 + 1: kern = fwd6_kernel<nb, true>; break;
+    TE_FWD6_CASE(1) TE_FWD6_CASE(2) TE_FWD6_CASE(3) TE_FWD6_CASE(4) TE_FWD6_CASE(5) TE_FWD6_CASE(6) TE_FWD6_CASE(7)
+#undef TE_FWD6_CASE
+    default: return TE_ERR_UNSUPPORTED;
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   kern<<<dim3((unsigned)(B * H)), dim3(kT), lds, stream>>>(qkv, z_qk, attn, out, (int)H, (int)N, scale, (unsigned char*)out_planes,
