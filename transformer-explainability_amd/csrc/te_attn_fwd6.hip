@@ -23,6 +23,8 @@
 //     one's stores and exponentials run beside another's MFMAs.
 //
 // Every reduction has a fixed order that depends on N only: a batch equals its samples run one by one, bit for bit.
+#include <type_traits>
+
 #include "te_common.h"
 
 namespace te_attn_fwd6 {
@@ -162,7 +164,16 @@ __device__ __forceinline__ void store_piece(float* __restrict__ row, int j0, int
 // through a wave-private LDS tile (row stride 144 B: conflict-free 16-byte writes), so that a store instruction covers 128 contiguous
 // bytes of each of 8 rows instead of 32 bytes of each of 32 (the texture addresser's rate: profiles/r06_attention_qk_rc_phases.log).
 constexpr int kTileLd = 36;                                 // floats per tile row
-__device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16& a, float* __restrict__ base, int i0, int j0, int N) {
+// LAST = the key block that may straddle N: its pieces are guarded per lane.  Every other block leaves as buffer stores whose hardware
+// range check (descriptor = the (b, h)'s N x N matrix) drops the rows at or beyond N: no branch, no exec masking, 32-bit offsets.
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+#ifdef TE_FWD6_NO_BUFSTORE
+constexpr bool kNoBufStore = true;      // measurement builds: the global-store path for every block
+#else
+constexpr bool kNoBufStore = false;
+#endif
+template <bool LAST>
+__device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16& a, float* __restrict__ base, Rsrc rs, int i0, int j0, int N) {
   const int lane = threadIdx.x & 63, n = lane & 31, kh = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -172,7 +183,19 @@ __device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16
   for (int m = 0; m < 4; ++m) {
     const int r = r8 + 8 * m;
     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * kTileLd + 4 * c);
-    if (i0 + r < N && j0 + 4 * c < N) store_piece(base + (int64_t)(i0 + r) * N, j0 + 4 * c, N, v);
+    if constexpr (LAST || kNoBufStore) {
+      if (i0 + r < N && j0 + 4 * c < N) store_piece(base + (int64_t)(i0 + r) * N, j0 + 4 * c, N, v);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (unsigned)(((i0 + r) * N + j0 + 4 * c) * 4), 0, 0);
+    }
+  }
+}
+
+template <int I, int END, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < END) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, END>(f);
   }
 }
 
@@ -210,6 +233,8 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
   const bool owner = wave < NB, row_ok = owner && i < N;
   float* z_bh = zqk + (int64_t)bh * N * N;
   float* a_bh = attn + (int64_t)bh * N * N;
+  const Rsrc z_rs = __builtin_amdgcn_make_buffer_rsrc(z_bh, 0, N * N * 4, 0x00020000);
+  const Rsrc a_rs = __builtin_amdgcn_make_buffer_rsrc(a_bh, 0, N * N * 4, 0x00020000);
 
   // ---- the wave's q rows as B planes in registers (requested before the k planes are staged: in flight beside the staging) ----
   bf16x8 qb[4][3];
@@ -263,10 +288,10 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
     }
     // ---- z_qk leaves, the row's softmax in registers ('dots = einsum(...) * self.scale', ViT_LRP.py:139-141) ----
     float mx = -INFINITY;
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
+    static_for<0, NB>([&](auto jbi) __attribute__((always_inline)) {
+      constexpr int jb = decltype(jbi)::value;
       {
-        block_out(tile, acc[jb], z_bh, wave * 32, 32 * jb, N);
+        block_out<(jb == NB - 1)>(tile, acc[jb], z_bh, z_rs, wave * 32, 32 * jb, N);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int j0 = 32 * jb + 8 * g + 4 * kh;
@@ -278,7 +303,7 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
           }
         }
       }
-    }
+    });
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.0f;
 #pragma unroll
@@ -294,8 +319,8 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
     sum = sum + __shfl_xor(sum, 32, 64);                   // (a + b = b + a: both lanes of a row hold the same bits)
     float rcs = __builtin_amdgcn_rcpf(sum);
     rcs = fmaf(fmaf(-sum, rcs, 1.0f), rcs, rcs);
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
+    static_for<0, NB>([&](auto jbi) __attribute__((always_inline)) {
+      constexpr int jb = decltype(jbi)::value;
       {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -303,9 +328,9 @@ __global__ __launch_bounds__(kT) void fwd6_kernel(const float* __restrict__ qkv,
           const f32x2 p1 = div2(f32x2{acc[jb][4 * g + 2], acc[jb][4 * g + 3]}, sum, rcs);
           acc[jb][4 * g] = p0[0], acc[jb][4 * g + 1] = p0[1], acc[jb][4 * g + 2] = p1[0], acc[jb][4 * g + 3] = p1[1];
         }
-        block_out(tile, acc[jb], a_bh, wave * 32, 32 * jb, N);
+        block_out<(jb == NB - 1)>(tile, acc[jb], a_bh, a_rs, wave * 32, 32 * jb, N);
       }
-    }
+    });
   }
   __syncthreads();                                         // every wave is done with the k planes
   write_vt(Pl, vreq, N, NS);
