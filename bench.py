@@ -252,7 +252,10 @@ KERNEL_GROUPS = {
                           "einsum 'bhij,bhjd->bhid' / MatMul rule, layers_ours.py:48-60"),
     "attention_qk_rule": ("qk_rule_kernel", "einsum 'bhid,bhjd->bhij' / MatMul rule, layers_ours.py:48-60"),
     "attention_fused_rules": ("attn_rules_kernel", "both attention rules of a ViT block in one pass, ViT_LRP.py:157-173"),
-    "attention_forward": ("attn_fwd_kernel", "producer: scores + softmax + attn v, ViT_LRP.py:132-152"),
+    "attention_forward": ("te_attn_fwd6::fwd6_kernel (N <= 224) / te_attn_fwd6l::fwd6l_kernel (64 < N <= 640, separate q / k / v, mask): row-block "
+                          "owners, bf16 MFMAs with split operands (the fp32-MFMA roof `frac` is priced against when the "
+                          "algorithmic fp32 flops outweigh the bytes is NOT the pipe these kernels run on: read `hbm_frac`)",
+                          "producer: scores + softmax + attn v, ViT_LRP.py:132-152, BERT.py:336-352"),
     "attention_backward": ("te_attn_kb::av6_kb_kernel<BWD> (d_attn, d_v) + qk_rule_kernel<BWD>", "producer: attention-gradient backward, "
                                                                          "ViT_LRP.py:144-145"),
     "layernorm_forward": ("ln_fwd_kernel", "producer: LayerNorm forward, layers_ours.py:76 (ViT_LRP.py:184,187,266)"),
@@ -297,7 +300,8 @@ def kernel_table(timer):
                "achieved": round(s["tflops"] if bound == "mfma" else s["tbs"], 4),
                "peak": mfma_peak(name) if bound == "mfma" else HBM_PEAK_TBS,
                "mfma_dtype": ("bf16 (executed flops)" if "x6" in name else "f32") if bound == "mfma" else None,
-               "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": round(max(t_f, t_b) / t, 4)}
+               "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": round(max(t_f, t_b) / t, 4),
+               "hbm_frac": round(t_b / t, 4)}
         out.append(row)
     out.sort(key=lambda r: -r["avg_us"] * r["launches"])
     return out

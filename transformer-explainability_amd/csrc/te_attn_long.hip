@@ -15,9 +15,19 @@
 //
 // fp32 MFMAs (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): exact k-ordered fma chains; every reduction has a fixed order that
 // depends on N only, so a batch equals its samples run one by one, bit for bit.
+#include <stdlib.h>
+#include <string.h>
+
 #include <algorithm>
 
 #include "te_common.h"
+
+namespace te_attn_fwd6l {      // te_attn_fwd6l.hip: row-block owners on bf16 MFMAs, two walks over the keys (round 6) -- the default forward, 64 < N <= 640
+bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
+int launch(const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+           const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn, const float* mask, float* z_qk, float* x_scaled, float* attn,
+           float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream);
+}  // namespace te_attn_fwd6l
 
 namespace {
 
@@ -462,6 +472,18 @@ extern "C" int te_attention_forward_strided_f32(const float* q, int64_t q_sb, in
       !strides_ok(o_sb, o_sh, o_sn))
     return TE_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
+#ifdef TE_STUDY      // TE_ATTN_FWD_LONG=old selects the round-3 kernel in measurement builds for same-box A/B runs
+  static const bool old_fwd = [] { const char* e = getenv("TE_ATTN_FWD_LONG"); return e && !strcmp(e, "old"); }();
+#else
+  constexpr bool old_fwd = false;
+#endif
+  if (!old_fwd && te_attn_fwd6l::supported(B, H, N, D)) {
+    const int rc = te_attn_fwd6l::launch(q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, v, v_sb, v_sh, v_sn, mask, z_qk, x_scaled, attn,
+                                         out, o_sb, o_sh, o_sn, B, H, N, scale, stream);
+    if (rc != TE_OK) return rc;
+    TE_RETURN_IF_LAUNCH_FAILED();
+    return TE_OK;
+  }
   allow_lds(attn_fwd_rows_kernel, lds_rows(NMAX));
   attn_fwd_rows_kernel<<<dim3((unsigned)(B * H * ntile)), dim3(kT), lds_rows(N), stream>>>(
       q, Strided{q_sb, q_sh, q_sn}, k, Strided{k_sb, k_sh, k_sn}, v, Strided{v_sb, v_sh, v_sn}, mask, z_qk, x_scaled, attn,
