@@ -439,6 +439,22 @@ int te_attention_backward_strided_f32(const float* d_out, int64_t do_sb, int64_t
                                       float* d_v, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
                                       int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk,
                                       void* ws, size_t ws_bytes, te_stream_t stream);
+/* te_attention_backward_strided_f32 with the block's forward output `out` ([B,H,N,64] view, the tensor
+ * te_attention_forward_strided_f32 wrote) as one more operand: the softmax backward's row sums sum_j d_attn . attn are taken
+ * as d_out . out (out = attn v, d_attn = d_out v^T), which lets the row side run in ONE walk over the keys on bf16 MFMAs
+ * (csrc/te_attn_bwd6l.hip, 64 < N <= 640; other lengths: the kernels of te_attention_backward_strided_f32).  Replaces the same
+ * autograd nodes (ViT_LRP.py:144-145, BERT.py:349-350). */
+int te_attention_backward_strided_out_f32(const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn,
+                                          const float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                                          const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                                          const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                          const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                                          const float* attn, float* d_attn,
+                                          float* d_q, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,
+                                          float* d_k, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn,
+                                          float* d_v, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                                          int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk,
+                                          void* ws, size_t ws_bytes, te_stream_t stream);
 
 /* The LayerNorm and GELU layers around the Linear rules (modules/layers_ours.py:70-77; ViT_LRP.py:57,184,187,266;
  * BERT.py:18,52,416,463): their relprop rules are the identity, the path needs their forward values (the X / Y the

@@ -38,9 +38,9 @@ def main():
     if len(sys.argv) > 5 and sys.argv[5] == "producers" and ops.attention_forward_supported(N, D):
         qkv = torch.randn(B, N, 3 * H * D, device=d)
         g = torch.randn(B, N, H * D, device=d)
-        _, attn_p, _ = ops.attention_forward(qkv, H, D ** -0.5)
+        out_p, attn_p, _ = ops.attention_forward(qkv, H, D ** -0.5)
         fw = t(lambda: ops.attention_forward(qkv, H, D ** -0.5))
-        bw = t(lambda: ops.attention_backward(g, qkv, attn_p, H, D ** -0.5))
+        bw = t(lambda: ops.attention_backward(g, qkv, attn_p, H, D ** -0.5, out=out_p))
         print(f"B={B} H={H} N={N}: producer forward {fw:7.1f} us   backward {bw:7.1f} us")
     nn = B * H * N * N * 4 / 1e6
     print(f"B={B} H={H} N={N}: AV rule {av:7.1f} us   QK rule {qk:7.1f} us   (one [B,H,N,N] tensor = {nn:.0f} MB)")

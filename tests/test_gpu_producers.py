@@ -84,7 +84,13 @@ def test_attention_backward_producer(B, H, N, need_qk):
         # and a batch equals its samples bit for bit
         out_k, attn_k2, _ = ops.attention_forward(qkv.detach(), H, scale)
         d_attn2, d_qkv2 = ops.attention_backward(g_out, qkv.detach(), attn_k2, H, scale, need_qk=True, out=out_k)
-        assert torch.equal(d_attn2, d_attn) and torch.equal(d_qkv2[..., 2 * C:], d_qkv[..., 2 * C:])
+        # (beyond 224 tokens the row side with `out` is te_attn_bwd6l.hip -- bf16 MFMAs with split operands -- and without it the
+        #  fp32-MFMA kernel of round 3: d_attn agrees to rounding there, not bit for bit; d_v comes from the same column kernel)
+        if N <= 224:
+            assert torch.equal(d_attn2, d_attn)
+        else:
+            check(f"producer.bwd_out.d_attn({B},{H},{N})", d_attn2, attn.grad, 3e-6)
+        assert torch.equal(d_qkv2[..., 2 * C:], d_qkv[..., 2 * C:])
         # The bar: 1e-5 of the gradient's maximum or -- where the softmax backward cancels, d_s = attn (d_attn - rowsum) ~ 0, at
         # N = 1 exactly 0 -- of the magnitude of the terms that cancel (scale |d_attn| |k|): the row sum is the same quantity
         # summed another way, so what is left of a cancellation is rounding of that size, not of the result's.
@@ -146,6 +152,18 @@ def test_attention_producer_bert_layout(B, H, N, masked):
         if need_qk:
             check("producer.bert.d_q" + tag, d_q, q.grad, 1e-5)
             check("producer.bert.d_k" + tag, d_k, k.grad, 1e-5)
+    # with the forward output at hand (te_attention_backward_strided_out_f32: row sums from d_out . out; beyond 64 tokens the row
+    # side on te_attn_bwd6l.hip): the same bars, and sample 0 alone == sample 0 of the batch, bitwise
+    d_q, d_k, d_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    d_attn = ops.attention_backward_qkv(g_out, q.detach(), k.detach(), v.detach(), attn, H, scale, d_q, d_k, d_v, need_qk=True, out=out)
+    check("producer.bert_out.d_attn" + tag, d_attn, probs.grad, 3e-6)
+    check("producer.bert_out.d_v" + tag, d_v, v.grad, 3e-6)
+    check("producer.bert_out.d_q" + tag, d_q, q.grad, 1e-5)
+    check("producer.bert_out.d_k" + tag, d_k, k.grad, 1e-5)
+    d_q1, d_k1, d_v1 = torch.empty_like(q[:1]), torch.empty_like(k[:1]), torch.empty_like(v[:1])
+    d_attn1 = ops.attention_backward_qkv(g_out[:1].contiguous(), q.detach()[:1], k.detach()[:1], v.detach()[:1], attn[:1].contiguous(), H,
+                                         scale, d_q1, d_k1, d_v1, need_qk=True, out=out[:1].contiguous())
+    assert torch.equal(d_attn1, d_attn[:1]) and torch.equal(d_q1, d_q[:1]) and torch.equal(d_k1, d_k[:1]) and torch.equal(d_v1, d_v[:1])
     # sample 0 alone == sample 0 of the batch, bitwise
     one = ops.attention_forward_qkv(q.detach()[:1], k.detach()[:1], v.detach()[:1], H, scale,
                                     mask=None if mask is None else mask[:1], want_z=True, want_x=masked)

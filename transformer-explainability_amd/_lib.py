@@ -63,6 +63,9 @@ SIGNATURES = {
     "te_attention_backward_strided_f32": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64,
                                                _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64,
                                                _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
+    "te_attention_backward_strided_out_f32": (_I, [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64,
+                                                   _P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _P,
+                                                   _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I, _P, _SZ, _P]),
     "te_linear_relprop_x6_supported": (_I, [_I64, _I64, _I64]),
     "te_linear_relprop_x6_workspace_bytes": (_SZ, [_I64, _I64, _I64]),
     "te_linear_x6_weight_planes_bytes": (_SZ, [_I64, _I64]),

@@ -51,7 +51,7 @@ class _FusedSelfAttention(torch.autograd.Function):
     def forward(ctx, q, k, v, mask, num_heads, scale, module):
         out, attn, zqk, xsc = ops.attention_forward_qkv(q, k, v, num_heads, scale, mask=mask, want_z=True,
                                                         want_x=mask is not None)
-        ctx.save_for_backward(q, k, v, attn)
+        ctx.save_for_backward(q, k, v, attn, out)      # (out: the softmax backward's row sums are d_out . out)
         ctx.num_heads, ctx.scale, ctx.module = num_heads, scale, module
         if xsc is None:
             xsc = zqk.new_empty(0)
@@ -61,14 +61,14 @@ class _FusedSelfAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, _a, _z, _x):
-        q, k, v, attn = ctx.saved_tensors
+        q, k, v, attn, out = ctx.saved_tensors
         if d_out is None:
             return None, None, None, None, None, None, None
         stop = bool(getattr(ctx.module, "_fused_stop_backward", False))
         d_v = torch.empty_like(v)
         d_q = None if stop else torch.empty_like(q)
         d_k = None if stop else torch.empty_like(k)
-        d_attn = ops.attention_backward_qkv(d_out, q, k, v, attn, ctx.num_heads, ctx.scale, d_q, d_k, d_v, need_qk=not stop)
+        d_attn = ops.attention_backward_qkv(d_out, q, k, v, attn, ctx.num_heads, ctx.scale, d_q, d_k, d_v, need_qk=not stop, out=out)
         ctx.module.save_attn_gradients(d_attn)
         if stop:
             return None, None, None, None, None, None, None

@@ -24,7 +24,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libte_relprop.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 
-SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_linear_x6.hip", "te_attn.hip", "te_attn_mfma.hip", "te_attn_rules.hip", "te_attn_kb.hip", "te_attn_rc.hip", "te_attn_fwd6.hip", "te_attn_fwd6l.hip", "te_attn_long.hip", "te_norm_act.hip",
+SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_linear_x6.hip", "te_attn.hip", "te_attn_mfma.hip", "te_attn_rules.hip", "te_attn_kb.hip", "te_attn_rc.hip", "te_attn_fwd6.hip", "te_attn_fwd6l.hip", "te_attn_bwd6l.hip", "te_attn_long.hip", "te_norm_act.hip",
            "te_rollout.hip", "te_heatmap.hip", "te_conv.hip", "te_perturb.hip"]
 
 CXXFLAGS = [
@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "te_common.h"), os.path.join(INCLUDE, "te_relprop.h"), __file__]
+    headers = [os.path.join(CSRC, "te_common.h"), os.path.join(CSRC, "te_attn_l6.h"), os.path.join(INCLUDE, "te_relprop.h"), __file__]
     # measurement builds only (benchmarks/, scripts/): TE_BUILD_DEFINES="TE_X6_STUDY" adds -D flags; they are built NEXT TO the
     # shipped library (lib/libte_relprop_study.so, objects in build_study/) and selected with TE_RELPROP_LIB, so that a
     # measurement never replaces the library the tests load

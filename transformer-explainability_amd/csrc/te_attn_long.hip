@@ -29,6 +29,14 @@ int launch(const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float
            float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream);
 }  // namespace te_attn_fwd6l
 
+namespace te_attn_bwd6l {      // te_attn_bwd6l.hip: the row side of the backward pass in the same structure (round 6), 64 < N <= 640
+bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
+int launch_rows(const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn, const float* out, int64_t o_sb, int64_t o_sh,
+                int64_t o_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* v, int64_t v_sb, int64_t v_sh,
+                int64_t v_sn, const float* attn, float* d_attn, float* rowdot, float* d_q, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,
+                int64_t B, int64_t H, int64_t N, float scale, int need_qk, hipStream_t stream);
+}  // namespace te_attn_bwd6l
+
 namespace {
 
 constexpr int TI = 32;          // query rows (or keys) per workgroup
@@ -492,6 +500,51 @@ extern "C" int te_attention_forward_strided_f32(const float* q, int64_t q_sb, in
   return TE_OK;
 }
 
+// out (optional): the forward output attention_forward returned for these inputs ([B,H,N,64] view).  With it -- or with
+// need_qk = 0, where no row sum is needed -- the row side runs on te_attn_bwd6l.hip (row sums from d_out . out); without it
+// on attn_bwd_rows_kernel (row sums from d_attn . attn).
+static int backward_strided(const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn, const float* out, int64_t o_sb,
+                            int64_t o_sh, int64_t o_sn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k,
+                            int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* v, int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                            const float* attn, float* d_attn, float* d_q, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn, float* d_k,
+                            int64_t dk_sb, int64_t dk_sh, int64_t dk_sn, float* d_v, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                            int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk, void* ws, size_t ws_bytes,
+                            te_stream_t stream_) {
+  if (!d_out || !k || !v || !attn || !d_attn || !d_v || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
+  if (need_qk && (!q || !d_q || !d_k)) return TE_ERR_INVALID_ARG;
+  const int64_t ntile = te_ceil_div(N, TI);
+  if (!te_attention_strided_supported(N, D) || B * H * ntile > 0x7fffffff) return TE_ERR_UNSUPPORTED;
+  if (!strides_ok(do_sb, do_sh, do_sn) || !strides_ok(k_sb, k_sh, k_sn) || !strides_ok(v_sb, v_sh, v_sn) ||
+      !strides_ok(dv_sb, dv_sh, dv_sn) || (out && !strides_ok(o_sb, o_sh, o_sn)))
+    return TE_ERR_UNSUPPORTED;
+  if (need_qk && (!strides_ok(q_sb, q_sh, q_sn) || !strides_ok(dq_sb, dq_sh, dq_sn) || !strides_ok(dk_sb, dk_sh, dk_sn)))
+    return TE_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < te_attention_backward_strided_workspace_bytes(B, H, N)) return TE_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* rowdot = (float*)ws;
+#ifdef TE_STUDY      // TE_ATTN_BWD_LONG=old selects the round-3 row kernel in measurement builds for same-box A/B runs
+  static const bool old_rows = [] { const char* e = getenv("TE_ATTN_BWD_LONG"); return e && !strcmp(e, "old"); }();
+#else
+  constexpr bool old_rows = false;
+#endif
+  if (!old_rows && (out || !need_qk) && te_attn_bwd6l::supported(B, H, N, D)) {
+    const int rc = te_attn_bwd6l::launch_rows(d_out, do_sb, do_sh, do_sn, out, o_sb, o_sh, o_sn, k, k_sb, k_sh, k_sn, v, v_sb, v_sh, v_sn,
+                                              attn, d_attn, rowdot, d_q, dq_sb, dq_sh, dq_sn, B, H, N, scale, need_qk ? 1 : 0, stream);
+    if (rc != TE_OK) return rc;
+  } else {
+    allow_lds(attn_bwd_rows_kernel, lds_rows(NMAX));
+    attn_bwd_rows_kernel<<<dim3((unsigned)(B * H * ntile)), dim3(kT), lds_rows(N), stream>>>(
+        d_out, Strided{do_sb, do_sh, do_sn}, k, Strided{k_sb, k_sh, k_sn}, v, Strided{v_sb, v_sh, v_sn}, attn, d_attn, rowdot,
+        d_q, Strided{dq_sb, dq_sh, dq_sn}, (int)H, (int)N, (int)ntile, scale, need_qk ? 1 : 0);
+  }
+  const int64_t nwg = te_ceil_div(ntile, 4);       // four key blocks (waves) per workgroup
+  attn_bwd_cols_kernel<<<dim3((unsigned)(B * H * nwg)), dim3(kTC), 0, stream>>>(
+      attn, d_attn, rowdot, d_out, Strided{do_sb, do_sh, do_sn}, q, Strided{q_sb, q_sh, q_sn}, d_v,
+      Strided{dv_sb, dv_sh, dv_sn}, d_k, Strided{dk_sb, dk_sh, dk_sn}, (int)H, (int)N, (int)nwg, scale, need_qk ? 1 : 0);
+  TE_RETURN_IF_LAUNCH_FAILED();
+  return TE_OK;
+}
+
 extern "C" int te_attention_backward_strided_f32(const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn,
                                                  const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k,
                                                  int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* v, int64_t v_sb,
@@ -500,26 +553,22 @@ extern "C" int te_attention_backward_strided_f32(const float* d_out, int64_t do_
                                                  int64_t dk_sh, int64_t dk_sn, float* d_v, int64_t dv_sb, int64_t dv_sh,
                                                  int64_t dv_sn, int64_t B, int64_t H, int64_t N, int64_t D, float scale,
                                                  int need_qk, void* ws, size_t ws_bytes, te_stream_t stream_) {
-  if (!d_out || !k || !v || !attn || !d_attn || !d_v || B <= 0 || H <= 0 || N <= 0) return TE_ERR_INVALID_ARG;
-  if (need_qk && (!q || !d_q || !d_k)) return TE_ERR_INVALID_ARG;
-  const int64_t ntile = te_ceil_div(N, TI);
-  if (!te_attention_strided_supported(N, D) || B * H * ntile > 0x7fffffff) return TE_ERR_UNSUPPORTED;
-  if (!strides_ok(do_sb, do_sh, do_sn) || !strides_ok(k_sb, k_sh, k_sn) || !strides_ok(v_sb, v_sh, v_sn) ||
-      !strides_ok(dv_sb, dv_sh, dv_sn))
-    return TE_ERR_UNSUPPORTED;
-  if (need_qk && (!strides_ok(q_sb, q_sh, q_sn) || !strides_ok(dq_sb, dq_sh, dq_sn) || !strides_ok(dk_sb, dk_sh, dk_sn)))
-    return TE_ERR_UNSUPPORTED;
-  if (!ws || ws_bytes < te_attention_backward_strided_workspace_bytes(B, H, N)) return TE_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
-  float* rowdot = (float*)ws;
-  allow_lds(attn_bwd_rows_kernel, lds_rows(NMAX));
-  attn_bwd_rows_kernel<<<dim3((unsigned)(B * H * ntile)), dim3(kT), lds_rows(N), stream>>>(
-      d_out, Strided{do_sb, do_sh, do_sn}, k, Strided{k_sb, k_sh, k_sn}, v, Strided{v_sb, v_sh, v_sn}, attn, d_attn, rowdot,
-      d_q, Strided{dq_sb, dq_sh, dq_sn}, (int)H, (int)N, (int)ntile, scale, need_qk ? 1 : 0);
-  const int64_t nwg = te_ceil_div(ntile, 4);       // four key blocks (waves) per workgroup
-  attn_bwd_cols_kernel<<<dim3((unsigned)(B * H * nwg)), dim3(kTC), 0, stream>>>(
-      attn, d_attn, rowdot, d_out, Strided{do_sb, do_sh, do_sn}, q, Strided{q_sb, q_sh, q_sn}, d_v,
-      Strided{dv_sb, dv_sh, dv_sn}, d_k, Strided{dk_sb, dk_sh, dk_sn}, (int)H, (int)N, (int)nwg, scale, need_qk ? 1 : 0);
-  TE_RETURN_IF_LAUNCH_FAILED();
-  return TE_OK;
+  return backward_strided(d_out, do_sb, do_sh, do_sn, nullptr, 0, 0, 0, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, v, v_sb, v_sh, v_sn,
+                          attn, d_attn, d_q, dq_sb, dq_sh, dq_sn, d_k, dk_sb, dk_sh, dk_sn, d_v, dv_sb, dv_sh, dv_sn, B, H, N, D, scale,
+                          need_qk, ws, ws_bytes, stream_);
+}
+
+extern "C" int te_attention_backward_strided_out_f32(const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn,
+                                                     const float* out, int64_t o_sb, int64_t o_sh, int64_t o_sn, const float* q,
+                                                     int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb,
+                                                     int64_t k_sh, int64_t k_sn, const float* v, int64_t v_sb, int64_t v_sh,
+                                                     int64_t v_sn, const float* attn, float* d_attn, float* d_q, int64_t dq_sb,
+                                                     int64_t dq_sh, int64_t dq_sn, float* d_k, int64_t dk_sb, int64_t dk_sh,
+                                                     int64_t dk_sn, float* d_v, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                                                     int64_t B, int64_t H, int64_t N, int64_t D, float scale, int need_qk, void* ws,
+                                                     size_t ws_bytes, te_stream_t stream_) {
+  if (!out) return TE_ERR_INVALID_ARG;
+  return backward_strided(d_out, do_sb, do_sh, do_sn, out, o_sb, o_sh, o_sn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, v, v_sb, v_sh,
+                          v_sn, attn, d_attn, d_q, dq_sb, dq_sh, dq_sn, d_k, dk_sb, dk_sh, dk_sn, d_v, dv_sb, dv_sh, dv_sn, B, H, N, D,
+                          scale, need_qk, ws, ws_bytes, stream_);
 }

@@ -671,9 +671,12 @@ def attention_forward_qkv(q: Tensor, k: Tensor, v: Tensor, num_heads: int, scale
 
 
 def attention_backward_qkv(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, attn: Tensor, num_heads: int, scale: float,
-                           d_q: Optional[Tensor], d_k: Optional[Tensor], d_v: Tensor, need_qk: bool = True) -> Tensor:
+                           d_q: Optional[Tensor], d_k: Optional[Tensor], d_v: Tensor, need_qk: bool = True,
+                           out: Optional[Tensor] = None) -> Tensor:
     """Gradient of attention_forward_qkv: d_out [B,N,C]; d_q / d_k / d_v: [B,N,C] views written in place (d_q, d_k may be
-    None with need_qk=False).  Returns d_attn [B,H,N,N]."""
+    None with need_qk=False).  Returns d_attn [B,H,N,N].  out: the forward output [B,N,C] attention_forward_qkv returned for
+    these inputs, if the caller still holds it -- the softmax backward's row sums are then d_out . out and the row side runs
+    on csrc/te_attn_bwd6l.hip (te_attention_backward_strided_out_f32)."""
     B, N, C = d_out.shape
     H, D = num_heads, C // num_heads
     d_out, attn = _c(d_out), _c(attn)
@@ -684,6 +687,14 @@ def attention_backward_qkv(d_out: Tensor, q: Tensor, k: Tensor, v: Tensor, attn:
     with _on_device(d_out) as lib, _timed("attention_backward", (8.0 if need_qk else 4.0) * B * H * N * N * D,
                                           4.0 * B * ((4 if need_qk else 2) * H * N * N + 8 * N * C)):
         ws = _ws(lib.te_attention_backward_strided_workspace_bytes(B, H, N), d_out)
+        if out is not None and tuple(out.shape) == (B, N, C) and out.dtype == d_out.dtype and out.stride(-1) == 1:
+            (o, ob, oh, on) = _heads(_prep(out), H)
+            _lib.check(lib.te_attention_backward_strided_out_f32(_ptr(d_out), N * C, 64, C, _ptr(o), ob, oh, on, _ptr(q), qb, qh, qn,
+                                                                 _ptr(k), kb, kh, kn, _ptr(v), vb, vh, vn, _ptr(attn), _ptr(d_attn),
+                                                                 _ptr(dq), dqb, dqh, dqn, _ptr(dk), dkb, dkh, dkn, _ptr(dv), dvb, dvh,
+                                                                 dvn, B, H, N, D, float(scale), int(bool(need_qk)), _ptr(ws),
+                                                                 ws.numel(), _stream(d_out)), "te_attention_backward_strided_out_f32")
+            return d_attn
         _lib.check(lib.te_attention_backward_strided_f32(_ptr(d_out), N * C, 64, C, _ptr(q), qb, qh, qn, _ptr(k), kb, kh, kn,
                                                          _ptr(v), vb, vh, vn, _ptr(attn), _ptr(d_attn), _ptr(dq), dqb, dqh,
                                                          dqn, _ptr(dk), dkb, dkh, dkn, _ptr(dv), dvb, dvh, dvn, B, H, N, D,
@@ -745,7 +756,7 @@ def attention_backward(d_out: Tensor, qkv: Tensor, attn: Tensor, num_heads: int,
     if not _lib.load().te_attention_forward_supported(N, D):
         th = lambda t, i: t[..., i * C:(i + 1) * C]      # noqa: E731
         d_attn = attention_backward_qkv(d_out, th(qkv, 0), th(qkv, 1), th(qkv, 2), attn, num_heads, scale,
-                                        th(d_qkv, 0), th(d_qkv, 1), th(d_qkv, 2), need_qk=need_qk)
+                                        th(d_qkv, 0), th(d_qkv, 1), th(d_qkv, 2), need_qk=need_qk, out=out)
         return d_attn, d_qkv
     d_attn = torch.empty_like(attn)
     with _on_device(qkv) as lib, _timed("attention_backward", (8.0 if need_qk else 4.0) * B * H * N * N * D,
