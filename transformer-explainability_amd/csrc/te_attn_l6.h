@@ -89,22 +89,24 @@ __device__ __forceinline__ void write_k(unsigned char* __restrict__ Pk, const KR
 struct VReq {
   float x[8];
 };
-template <int W>
+// PERM = false: the plain K order, element t = row kKC c + 16 step + 8 kh + t (a B operand loaded straight from memory: the column
+// side of the backward pass, whose K index is the query row)
+template <int W, bool PERM = true>
 __device__ __forceinline__ void request_v(VReq& r, const float* __restrict__ v, int64_t sn, int N, int c) {
   const int d = threadIdx.x & 63, g8 = threadIdx.x >> 6, step = g8 >> 1, kh = g8 & 1;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const int row = Cfg<W>::kKC * c + 16 * step + 8 * (t >> 2) + 4 * kh + (t & 3);
+    const int row = Cfg<W>::kKC * c + 16 * step + (PERM ? 8 * (t >> 2) + 4 * kh + (t & 3) : 8 * kh + t);
     r.x[t] = v[(int64_t)min(row, N - 1) * sn + d];
   }
 }
-template <int W>
+template <int W, bool PERM = true>
 __device__ __forceinline__ void write_v(unsigned char* __restrict__ Pv, const VReq& r, int N, int c) {
   const int d = threadIdx.x & 63, g8 = threadIdx.x >> 6, step = g8 >> 1, kh = g8 & 1;
   float x[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const int row = Cfg<W>::kKC * c + 16 * step + 8 * (t >> 2) + 4 * kh + (t & 3);
+    const int row = Cfg<W>::kKC * c + 16 * step + (PERM ? 8 * (t >> 2) + 4 * kh + (t & 3) : 8 * kh + t);
     x[t] = (row < N) ? r.x[t] : 0.0f;
   }
   bf16x8 b[3];

@@ -35,6 +35,9 @@ int launch_rows(const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn,
                 int64_t o_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn, const float* v, int64_t v_sb, int64_t v_sh,
                 int64_t v_sn, const float* attn, float* d_attn, float* rowdot, float* d_q, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,
                 int64_t B, int64_t H, int64_t N, float scale, int need_qk, hipStream_t stream);
+int launch_cols(const float* attn, const float* d_attn, const float* rowdot, const float* d_out, int64_t do_sb, int64_t do_sh, int64_t do_sn,
+                const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, float* d_v, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn, float* d_k,
+                int64_t dk_sb, int64_t dk_sh, int64_t dk_sn, int64_t B, int64_t H, int64_t N, float scale, int need_qk, hipStream_t stream);
 }  // namespace te_attn_bwd6l
 
 namespace {
@@ -536,6 +539,18 @@ static int backward_strided(const float* d_out, int64_t do_sb, int64_t do_sh, in
     attn_bwd_rows_kernel<<<dim3((unsigned)(B * H * ntile)), dim3(kT), lds_rows(N), stream>>>(
         d_out, Strided{do_sb, do_sh, do_sn}, k, Strided{k_sb, k_sh, k_sn}, v, Strided{v_sb, v_sh, v_sn}, attn, d_attn, rowdot,
         d_q, Strided{dq_sb, dq_sh, dq_sn}, (int)H, (int)N, (int)ntile, scale, need_qk ? 1 : 0);
+  }
+#ifdef TE_STUDY      // TE_ATTN_BWD_COLS=old selects the round-3 column kernel in measurement builds
+  static const bool old_cols = [] { const char* e = getenv("TE_ATTN_BWD_COLS"); return e && !strcmp(e, "old"); }();
+#else
+  constexpr bool old_cols = false;
+#endif
+  if (!old_cols && te_attn_bwd6l::supported(B, H, N, D)) {
+    const int rc = te_attn_bwd6l::launch_cols(attn, d_attn, rowdot, d_out, do_sb, do_sh, do_sn, q, q_sb, q_sh, q_sn, d_v, dv_sb, dv_sh, dv_sn,
+                                              d_k, dk_sb, dk_sh, dk_sn, B, H, N, scale, need_qk ? 1 : 0, stream);
+    if (rc != TE_OK) return rc;
+    TE_RETURN_IF_LAUNCH_FAILED();
+    return TE_OK;
   }
   const int64_t nwg = te_ceil_div(ntile, 4);       // four key blocks (waves) per workgroup
   attn_bwd_cols_kernel<<<dim3((unsigned)(B * H * nwg)), dim3(kTC), 0, stream>>>(
