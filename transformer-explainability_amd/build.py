@@ -24,7 +24,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libte_relprop.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 
-SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_linear_x6.hip", "te_attn.hip", "te_attn_mfma.hip", "te_attn_rules.hip", "te_attn_kb.hip", "te_attn_rc.hip", "te_attn_fwd6.hip", "te_attn_fwd6l.hip", "te_attn_bwd6l.hip", "te_attn_qk6l.hip", "te_attn_long.hip", "te_norm_act.hip",
+SOURCES = ["te_api.hip", "te_elementwise.hip", "te_linear.hip", "te_linear_x6.hip", "te_attn.hip", "te_attn_mfma.hip", "te_attn_rules.hip", "te_attn_kb.hip", "te_attn_rc.hip", "te_attn_fwd6.hip", "te_attn_fwd6l.hip", "te_attn_bwd6l.hip", "te_attn_long.hip", "te_norm_act.hip",
            "te_rollout.hip", "te_heatmap.hip", "te_conv.hip", "te_perturb.hip"]
 
 CXXFLAGS = [

@@ -216,22 +216,4 @@ __device__ __forceinline__ void block_in_land(float* __restrict__ tile, const f3
   }
 }
 
-// safe_divide (modules/layers_ours.py:10-13) of two element pairs on packed fp32 instructions (te_attn_rc.hip: sd2): den = b + 1e-9
-// (one rounding), an exact-zero den replaced by 1e-9, a / den formed as in the hardware's own expansion of an IEEE division without
-// its range scaling -- correctly rounded wherever no intermediate leaves the normal range --, zero where b == 0.
-__device__ __forceinline__ f32x2 sd2(f32x2 a, f32x2 b) {
-  f32x2 den = b + f32x2{1e-9f, 1e-9f};
-  den[0] = (den[0] == 0.0f) ? 1e-9f : den[0];
-  den[1] = (den[1] == 0.0f) ? 1e-9f : den[1];
-  f32x2 rc = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  const f32x2 e = __builtin_elementwise_fma(-den, rc, f32x2{1.0f, 1.0f});
-  rc = __builtin_elementwise_fma(e, rc, rc);
-  f32x2 q = a * rc;
-  const f32x2 r = __builtin_elementwise_fma(-den, q, a);
-  q = __builtin_elementwise_fma(r, rc, q);
-  q[0] = (b[0] != 0.0f) ? q[0] : 0.0f;
-  q[1] = (b[1] != 0.0f) ? q[1] : 0.0f;
-  return q;
-}
-
 }  // namespace te_attn_l6

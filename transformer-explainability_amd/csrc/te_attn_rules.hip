@@ -68,14 +68,6 @@ int qk_launch(int mode, const float* Rnn, const float* q, int64_t q_sb, int64_t 
               int64_t o_sh = 0, int64_t o_sn = 0);
 }  // namespace te_attn_rc
 
-namespace te_attn_qk6l {      // te_attn_qk6l.hip: the QK rule beyond 224 tokens in the structure of te_attn_bwd6l.hip (round 6), 64 < N <= 640
-bool supported(int64_t B, int64_t H, int64_t N, int64_t D, int64_t q_sb, int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn,
-               int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn);
-int launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int64_t q_sn, const float* k, int64_t k_sb, int64_t k_sh, int64_t k_sn,
-           const float* Z, float* cam_q, int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, float* cam_k, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
-           int64_t B, int64_t H, int64_t N, float scale, const float* r_scale, int64_t r_scale_stride, hipStream_t stream);
-}  // namespace te_attn_qk6l
-
 namespace te_attn_fwd6 {      // te_attn_fwd6.hip: row-block owners on bf16 MFMAs (round 6) -- the default attention forward, N <= 224
 bool supported(int64_t B, int64_t H, int64_t N, int64_t D);
 int launch(const float* qkv, float* z_qk, float* attn, float* out, int64_t B, int64_t H, int64_t N, float scale, hipStream_t stream,
@@ -1038,14 +1030,6 @@ int qk_launch(const float* Rnn, const float* q, int64_t q_sb, int64_t q_sh, int6
   if (use_rc_qk() && te_attn_rc::supported(B, H, N, 64))
     return te_attn_rc::qk_launch(0, Rnn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn, cam_k, ck_sb, ck_sh,
                                  ck_sn, B, H, N, scale, r_scale, r_scale_stride, stream);
-#ifdef TE_STUDY      // TE_ATTN_QK_LONG=old keeps qk_rule_kernel beyond 224 tokens in measurement builds
-  static const bool old_long = [] { const char* e = getenv("TE_ATTN_QK_LONG"); return e && !strcmp(e, "old"); }();
-#else
-  constexpr bool old_long = false;
-#endif
-  if (!old_long && use_rc_qk() && te_attn_qk6l::supported(B, H, N, 64, q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, cq_sb, cq_sh, cq_sn, ck_sb, ck_sh, ck_sn))
-    return te_attn_qk6l::launch(Rnn, q, q_sb, q_sh, q_sn, k, k_sb, k_sh, k_sn, Z, cam_q, cq_sb, cq_sh, cq_sn, cam_k, ck_sb, ck_sh, ck_sn, B, H, N,
-                                scale, r_scale, r_scale_stride, stream);
   if (use_kb_qk() && te_attn_kb::supported(B, H, N, 64)) {
     const Strided qs{q_sb, q_sh, q_sn}, cqs{cq_sb, cq_sh, cq_sn};
     int kng = 1;
