@@ -256,8 +256,9 @@ KERNEL_GROUPS = {
                           "owners, bf16 MFMAs with split operands (the fp32-MFMA roof `frac` is priced against when the "
                           "algorithmic fp32 flops outweigh the bytes is NOT the pipe these kernels run on: read `hbm_frac`)",
                           "producer: scores + softmax + attn v, ViT_LRP.py:132-152, BERT.py:336-352"),
-    "attention_backward": ("te_attn_kb::av6_kb_kernel<BWD> (d_attn, d_v) + qk_rule_kernel<BWD>", "producer: attention-gradient backward, "
-                                                                         "ViT_LRP.py:144-145"),
+    "attention_backward": ("N <= 224: te_attn_kb::av6_kb_kernel<BWD> (d_attn, d_v) + te_attn_rc::qk_rc_kernel<BWD>; 64 < N <= 640 (separate q / k / v): "
+                           "te_attn_bwd6l::bwd6l_rows_kernel (d_attn, d_q) + bwd6l_cols_kernel (d_v, d_k) -- bf16 MFMAs with split operands: "
+                           "read `hbm_frac`", "producer: attention-gradient backward, ViT_LRP.py:144-145, BERT.py:349-350"),
     "layernorm_forward": ("ln_fwd_kernel", "producer: LayerNorm forward, layers_ours.py:76 (ViT_LRP.py:184,187,266)"),
     "layernorm_backward": ("ln_bwd_kernel", "producer: LayerNorm input gradient (+ the bypass gradient of the residual "
                                             "block), ViT_LRP.py:203-205"),
