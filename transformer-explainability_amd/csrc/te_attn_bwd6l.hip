@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * W, 2) void bwd6l_rows_kernel(const float* __re
   if (need_qk) write_v<W>(Pl + kOperand, kr, N, 0);
   __syncthreads();
 
-  const int i0 = blk * 32;
+  const RowOff ro = make_rowoff(blk * 32, N);
   const unsigned char* const lane_frag = Pl + lane * 16;
   f32x16 acc[NKB];
   f32x16 o[2];
@@ -118,15 +118,15 @@ __global__ __launch_bounds__(64 * W, 2) void bwd6l_rows_kernel(const float* __re
       f32x4 av[NKB][4];
       if (need_qk) {
 #pragma unroll
-        for (int u = 0; u < NKB; ++u) block_in_request(av[u], a_rs, i0, kKC * c + 32 * u, N);
+        for (int u = 0; u < NKB; ++u) block_in_request(av[u], a_rs, ro, kKC * c + 32 * u);
       }
       scores<W>(acc, buf, gb);                            // d_attn^T of the chunk: acc[u][4 g + e] <-> key kKC c + 32 u + 8 g + 4 h + e of row i
       if (last) {
 #pragma unroll
-        for (int u = 0; u < NKB; ++u) block_out<true>(tile, acc[u], d_rs, i0, kKC * c + 32 * u, N);
+        for (int u = 0; u < NKB; ++u) block_out<true>(tile, acc[u], d_rs, ro, kKC * c + 32 * u, N);
       } else {
 #pragma unroll
-        for (int u = 0; u < NKB; ++u) block_out<false>(tile, acc[u], d_rs, i0, kKC * c + 32 * u, N);
+        for (int u = 0; u < NKB; ++u) block_out<false>(tile, acc[u], d_rs, ro, kKC * c + 32 * u, N);
       }
       if (need_qk) {
 #pragma unroll

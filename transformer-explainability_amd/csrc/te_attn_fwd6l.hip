@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * W, 2) void fwd6l_kernel(const float* __restric
   write_k<W>(Pl, kr, N, 0);
   __syncthreads();
 
-  const int i0 = blk * 32;
+  const RowOff ro = make_rowoff(blk * 32, N);
   const unsigned char* const lane_frag = Pl + lane * 16;
   f32x16 acc[NKB];
   // x = acc * scale + (mask; -inf beyond N), in place
@@ -114,10 +114,10 @@ __global__ __launch_bounds__(64 * W, 2) void fwd6l_kernel(const float* __restric
     if constexpr (OPT & 1) return;
     if (tail) {
 #pragma unroll
-      for (int u = 0; u < NKB; ++u) block_out<true>(tile, a[u], rs, i0, kKC * c + 32 * u, N);
+      for (int u = 0; u < NKB; ++u) block_out<true>(tile, a[u], rs, ro, kKC * c + 32 * u, N);
     } else {
 #pragma unroll
-      for (int u = 0; u < NKB; ++u) block_out<false>(tile, a[u], rs, i0, kKC * c + 32 * u, N);
+      for (int u = 0; u < NKB; ++u) block_out<false>(tile, a[u], rs, ro, kKC * c + 32 * u, N);
     }
   };
 

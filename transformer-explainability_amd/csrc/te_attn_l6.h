@@ -142,8 +142,20 @@ __device__ __forceinline__ f32x2 sub2(float a, float b, float m) { return f32x2{
 // outside the descriptor (the (b, h)'s N x N matrix) and are dropped by the hardware; a piece at or beyond column N is sent there
 // on purpose (offset past the end); the piece that straddles N (N % 4 != 0, last chunk only: TAIL) goes out element by element.
 constexpr unsigned kDrop = 0xfffffff0u;
+// the byte offsets of a lane's four tile rows inside the (b, h)'s matrix at column 4 (lane & 7), formed once per kernel; a block's
+// column offset rides in the scalar offset of the buffer instruction: no vector address arithmetic per block
+struct RowOff {
+  unsigned v[4];
+};
+__device__ __forceinline__ RowOff make_rowoff(int i0, int N) {
+  const int lane = threadIdx.x & 63, r8 = lane >> 3, c = lane & 7;
+  RowOff ro;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) ro.v[m] = (unsigned)(((i0 + r8 + 8 * m) * N + 4 * c) * 4);
+  return ro;
+}
 template <bool TAIL>
-__device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16& a, Rsrc rs, int i0, int j0, int N) {
+__device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16& a, Rsrc rs, const RowOff& ro, int j0, int N) {
   const int lane = threadIdx.x & 63, n = lane & 31, kh = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -154,8 +166,8 @@ __device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16
   for (int m = 0; m < 4; ++m) {
     const int r = r8 + 8 * m;
     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * kTileLd + 4 * c);
-    const unsigned off = (unsigned)(((i0 + r) * N + col) * 4);
     if constexpr (TAIL) {
+      const unsigned off = ro.v[m] + (unsigned)(j0 * 4);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (col + 3 < N) ? off : kDrop, 0, 0);
       if (col < N && col + 3 >= N) {
 #pragma unroll
@@ -163,7 +175,7 @@ __device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16
           if (col + e < N) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs, off + 4u * e, 0, 0);
       }
     } else {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ro.v[m], j0 * 4, 0);
     }
   }
 }
@@ -197,13 +209,9 @@ __device__ __forceinline__ void scores(f32x16 (&acc)[Cfg<W>::kNKB], const unsign
 // the wave's tile into the accumulator layout.  request: four 16-byte buffer loads (rows at or beyond N read as zero; a piece at or
 // beyond column N reads the next row's values or zero -- finite, and the caller multiplies them with zero planes); land: tile
 // round trip.
-__device__ __forceinline__ void block_in_request(f32x4 (&v)[4], Rsrc rs, int i0, int j0, int N) {
-  const int lane = threadIdx.x & 63, r8 = lane >> 3, c = lane & 7;
+__device__ __forceinline__ void block_in_request(f32x4 (&v)[4], Rsrc rs, const RowOff& ro, int j0) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const unsigned off = (unsigned)(((i0 + r8 + 8 * m) * N + j0 + 4 * c) * 4);
-    v[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-  }
+  for (int m = 0; m < 4; ++m) v[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ro.v[m], j0 * 4, 0));
 }
 __device__ __forceinline__ void block_in_land(float* __restrict__ tile, const f32x4 (&v)[4], f32x16& a) {
   const int lane = threadIdx.x & 63, n = lane & 31, kh = lane >> 5, r8 = lane >> 3, c = lane & 7;
