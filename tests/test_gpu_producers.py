@@ -14,6 +14,9 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(2, 12, 197), (1, 3, 50), (2, 4, 224), (1, 2, 33), (3, 2, 1), (1, 1, 32), (2, 2, 64),
           # beyond 224 tokens: the row-tile kernels of csrc/te_attn_long.hip (ViT-L/16-384: 577; BERT: 512)
           (1, 2, 577), (2, 3, 512), (1, 2, 225), (1, 1, 640), (1, 2, 300)]
+# round 6: the chunked long-sequence producers (csrc/te_attn_fwd6l.hip, te_attn_bwd6l.hip; 64 < N <= 640 through the strided entry
+# points) at their edges: the shortest sequence they take, one key past a chunk / a block boundary, both workgroup cuts (4 and 8 waves)
+L6_SHAPES = [(2, 2, 65), (1, 3, 96), (2, 1, 97), (1, 2, 129), (1, 1, 257), (1, 2, 639)]
 
 
 def _stock(qkv, H, scale):
@@ -107,7 +110,7 @@ def test_attention_backward_producer(B, H, N, need_qk):
 
 
 @pytest.mark.parametrize("B,H,N,masked", [(2, 12, 512, True), (2, 2, 128, True), (1, 3, 577, False), (3, 2, 40, True),
-                                            (1, 12, 512, False)])
+                                            (1, 12, 512, False)] + [(b, h, n, bool(i % 2)) for i, (b, h, n) in enumerate(L6_SHAPES)])
 def test_attention_producer_bert_layout(B, H, N, masked):
     """The BERT form (BERT.py:336-352): three separate 'b n (h d)' activations, scores / sqrt(D), additive padding mask,
     softmax, probs v -- forward by-products (unscaled scores, masked scaled scores, probabilities) and all gradients
