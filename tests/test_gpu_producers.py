@@ -16,7 +16,8 @@ SHAPES = [(2, 12, 197), (1, 3, 50), (2, 4, 224), (1, 2, 33), (3, 2, 1), (1, 1, 3
           (1, 2, 577), (2, 3, 512), (1, 2, 225), (1, 1, 640), (1, 2, 300)]
 # round 6: the chunked long-sequence producers (csrc/te_attn_fwd6l.hip, te_attn_bwd6l.hip; 64 < N <= 640 through the strided entry
 # points) at their edges: the shortest sequence they take, one key past a chunk / a block boundary, both workgroup cuts (4 and 8 waves)
-L6_SHAPES = [(2, 2, 65), (1, 3, 96), (2, 1, 97), (1, 2, 129), (1, 1, 257), (1, 2, 639)]
+L6_SHAPES = [(2, 2, 65), (1, 3, 96), (2, 1, 97), (1, 2, 129), (1, 1, 257), (1, 2, 639), (1, 1, 578), (2, 1, 131)]      # (N % 4 = 0 .. 3: the row tails)
+SHAPES = SHAPES + [(1, 2, 639), (1, 1, 578), (2, 1, 131), (1, 2, 65)]
 
 
 def _stock(qkv, H, scale):

@@ -172,7 +172,10 @@ __device__ __forceinline__ void block_out(float* __restrict__ tile, const f32x16
       if (col < N && col + 3 >= N) {
 #pragma unroll
         for (int e = 0; e < 3; ++e)
-          if (col + e < N) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs, off + 4u * e, 0, 0);
+          if (col + e < N) {
+            const float x = v[e];      // (a copy: __builtin_bit_cast of the vector-element lvalue v[e] read element 0 for every e)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, off + 4u * e, 0, 0);
+          }
       }
     } else {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ro.v[m], j0 * 4, 0);
