@@ -13,6 +13,11 @@
 //             cols  one wave per (b, h, 32 keys): d_v = attn^T d_out, d_k = d_s^T q over all N query rows, operands
 //                straight from global memory (the key block of a row is one 128-B line), accumulators in registers
 //
+// Round 6: for 64 < N <= 640 the entry points below dispatch to te_attn_fwd6l.hip (forward) and te_attn_bwd6l.hip (backward: the
+// column side always, the row side when the caller hands over the block's forward output or needs no d_q / d_k) -- bf16 MFMAs with
+// split operands, 1.4-2.2 x these kernels, which remain for N <= 64, for the backward without `out`, and as the comparison path of
+// the A/B scripts (TE_ATTN_FWD_LONG / TE_ATTN_BWD_LONG / TE_ATTN_BWD_COLS = old in measurement builds).
+//
 // fp32 MFMAs (v_mfma_f32_32x32x2_f32 / 16x16x4_f32): exact k-ordered fma chains; every reduction has a fixed order that
 // depends on N only, so a batch equals its samples run one by one, bit for bit.
 #include <stdlib.h>
