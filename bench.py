@@ -117,7 +117,7 @@ def parse_args(argv=None):
                          "step that feeds the roofline block always runs serially")
     ap.add_argument("--inflight", type=int, default=None,
                     help="consecutive steps (batches) in flight, each replayed / launched on its own HIP stream.  Default: 2 "
-                         "where the step is a replayed HIP graph (ViT-B/16 and the sweep: 925 vs 896 maps/s, same box, A B A B, "
+                         "where the step is a replayed HIP graph (ViT-B/16, the sweep and, since round 6, BERT-512: 925 vs 896 maps/s, same box, A B A B, "
                          "profiles/r04_inflight2.log), 1 for the eager configurations (a second ViT-L/16-384 step in flight would "
                          "be another 117 GB of activations)")
     ap.add_argument("--linear", choices=["x6", "fp32"], default="x6",
@@ -222,6 +222,12 @@ class KernelTimer:
         return {"launches": n, "launches_dropped_as_small": len(rows) - n, "avg_us": secs / n * 1e6,
                 "flops_per_launch": flops / n, "bytes_per_launch": nbytes / n,
                 "tflops": flops / secs / 1e12, "tbs": nbytes / secs / 1e12}
+
+
+# configurations whose step is replayed as a HIP graph, two batches in flight, by default (ViT-L/16-384: a second step in flight would be
+# another 117 GB of activations, and its graph alone measures -0.7 %: eager, one in flight; BERT-512: 354 vs 335 sequences/s, same box,
+# round 6)
+GRAPH_CONFIGS = ("vit_b16_224", "sweep50k", "bert_base_512")
 
 
 def mfma_peak(name):
@@ -764,7 +770,7 @@ def main():
         # two replayed steps in flight where the step is a HIP graph AND a second step's activations are affordable: a ViT-B
         # step holds ~0.38 GB per sample (24 GB at batch 64; the one-GPU sweep's batch of 256 would be 2 x 96 GB + the eager
         # probe step's 96 GB: out of memory on a 288 GB part -- found the hard way, trip t16)
-        graph = args.graph == "on" or (args.graph == "auto" and args.config in ("vit_b16_224", "sweep50k"))
+        graph = args.graph == "on" or (args.graph == "auto" and args.config in GRAPH_CONFIGS)
         args.inflight = 2 if (graph and B <= 64) else 1
     concurrent = args.overlap_backward == "on" or args.inflight > 1       # from the RESOLVED number of steps in flight
     ops.X6_TILE = {"auto": 2 if concurrent else 0, "lib": 0, "128": 1, "256": 2}[args.x6_tile]
@@ -788,7 +794,7 @@ def main():
     # their own and must never meet an open capture; replay afterwards is an ordinary launch.
     graphed = None
     lane_graphs = None           # --inflight N with graphs: one captured step (own static buffers) per lane
-    use_graph = args.graph == "on" or (args.graph == "auto" and args.config in ("vit_b16_224", "sweep50k"))
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.config in GRAPH_CONFIGS)
     if use_graph:
         try:
             if args.inflight == 1:
