@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU diagnosis: where do the device-to-device memcpys (__amd_rocclr_copyBuffer in the rocprofv3 tables) of a step come from?
 One eager step of a bench configuration under torch.profiler with Python stacks; prints the call sites of aten::copy_ / aten::clone /
-aten::contiguous with the bytes they move.    python scripts/find_copies.py bert_base_512 4"""
+aten::contiguous with the bytes they move.    python scripts/find_copies.py bert_base_512 4 [fp32]"""
 import collections
 import os
 import sys
@@ -18,6 +18,8 @@ args.overlap_backward = "on" if args.overlap_backward == "auto" else args.overla
 dev = torch.device("cuda:0")
 from transformer_explainability_amd import ops  # noqa: E402
 ops.USE_FUSED_PRODUCERS = True      # (bench.main: --producers fused, the default)
+if len(sys.argv) > 3 and sys.argv[3] == "fp32":      # the comparison run of the bench line: Linear layers on the fp32-MFMA kernels
+    ops.USE_LINEAR_X6 = False
 wl = bench.Workload(args, 0, dev)
 for _ in range(2):
     wl.eager(*wl.inputs)
